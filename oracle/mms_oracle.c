@@ -1,0 +1,88 @@
+/*
+ * oracle/mms_oracle.c -- CPU restatement of the reference's MMS hot path.
+ *
+ * ============================ TEST INFRASTRUCTURE ===========================
+ * This file is the parity CHECKER, not the product.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may build, load or
+ * call it.  Nothing under mms_answer_selection_amd/ links or imports it; the
+ * product path fails loudly when the HIP library is missing instead of
+ * falling back to this code.
+ * ============================================================================
+ *
+ * What it restates (reference = lxmeng/mms_answer_selection, a Caffe fork):
+ *   SimCrossLayer<Dtype>::{Forward,Backward}_cpu   src/caffe/layers/sim_cross_layer.cpp:83-163,166-307
+ *   SimMatrixLayer<Dtype>::{Forward,Backward}_cpu  src/caffe/layers/sim_matrix_layer.cpp:53-65,68-95
+ *   PairRankLossLayer<Dtype>::{Forward,Backward}_cpu src/caffe/layers/pair_rank_loss_layer.cpp:26-52,55-84
+ *   RankAccuracyLayer<Dtype>::Forward_cpu          src/caffe/layers/rank_accuracy_layer.cpp:36-50
+ * Same loop nests, same summation order, same float/double promotions
+ * (notably the double-typed `1e-9` divisor in the Euclidean backward).
+ *
+ * PARITY UNPINNED.  The reference ships no test, golden vector or fixture for
+ * any of these layers (src/caffe/test has none), and its
+ * sources cannot be compiled here without writing stand-ins for glog, gflags,
+ * boost, the protoc-generated caffe.pb.h and CBLAS, which this project does
+ * not do.  The restatement is therefore pinned only by (i) a line-by-line
+ * reading of the reference, cited per function, (ii) independent float64
+ * closed-form checks and (iii) finite-difference gradient checks in
+ * tests/test_oracle.py (the reference's own GradientChecker method,
+ * include/caffe/test/test_gradient_check_util.hpp:148-175).
+ *
+ * Third-party arithmetic: modes 0/2 and SimMatrix go through CBLAS in the
+ * reference (MKL, unpinned, un-vendored).  The stand-ins in the impl header
+ * use k-ascending sums; results that pass through them are compared at 1e-5,
+ * everything else (mode 1, PairRankLoss elementwise terms) bit-for-bit.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; the reference is
+ * built -O2 without FMA contraction on x86-64, Makefile:298).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define Dtype float
+#define SFX(x) x##_f32
+#define SQRT(x) sqrtf(x)
+#define FABS(x) fabsf(x)
+#include "mms_oracle_impl.h"
+#undef Dtype
+#undef SFX
+#undef SQRT
+#undef FABS
+
+#define Dtype double
+#define SFX(x) x##_f64
+#define SQRT(x) sqrt(x)
+#define FABS(x) fabs(x)
+#include "mms_oracle_impl.h"
+#undef Dtype
+#undef SFX
+#undef SQRT
+#undef FABS
+
+/* ---------------------------------------------------------------------------
+ * Timing helper for bench.py's cpu_baseline leg: `iters` forward+backward
+ * passes of SimCross mode `mode` on caller-provided buffers, single thread,
+ * returns seconds (CLOCK_MONOTONIC).  Mirrors the loop shape of `caffe time`
+ * (tools/caffe.cpp:318-385).
+ * ------------------------------------------------------------------------- */
+#include <time.h>
+double oracle_time_simcross_fwd_bwd_f32(int mode, int N, int W1, int W2, int D,
+                                        int M, const float* q, const float* a,
+                                        const float* W, const float* bias,
+                                        const float* top_diff, float* top,
+                                        float* norm0, float* norm1, float* dq,
+                                        float* da, float* dW, float* dbias,
+                                        int iters) {
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int it = 0; it < iters; ++it) {
+    oracle_simcross_forward_f32(mode, N, W1, W2, D, M, q, a, W, bias, top,
+                                norm0, norm1);
+    oracle_simcross_backward_f32(mode, N, W1, W2, D, M, q, a, W, bias != NULL,
+                                 top, top_diff, norm0, norm1, 1, 1, dq, da, dW,
+                                 dbias);
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
