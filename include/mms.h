@@ -1,0 +1,181 @@
+/*
+ * include/mms.h -- C ABI of libmms_hip.so: the MI355X (gfx950) implementation
+ * of the MMS metric-learning inner loop of lxmeng/mms_answer_selection.
+ *
+ * This is the drop-in boundary.  Each entry point replaces the body of one
+ * Caffe virtual of the reference (the file:line it replaces is cited per
+ * function; paths relative to the reference checkout).  A Caffe build binds
+ * them from Forward_gpu/Backward_gpu with blob->gpu_data()/mutable_gpu_diff()
+ * pointers (INTEGRATION.md shows the stub); tests bind them with ctypes.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  Every data pointer is DEVICE memory
+ *    (hipMalloc / torch.cuda tensor), row-major contiguous, laid out exactly
+ *    like the reference's blobs.  No allocation, no host synchronisation, no
+ *    stream other than `stream` (a hipStream_t passed as void*; NULL = the
+ *    null stream, which is what Caffe uses).  Safe to capture in a hipGraph.
+ *  - Return value: MMS_OK or an MMS_ERR_* code; nothing is launched on error.
+ *    (The C++ Layer mirror turns a non-zero code into the reference's
+ *    CHECK/LOG(FATAL) abort.)
+ *  - Deterministic: no atomics; the same inputs give the same bits every run.
+ *  - Numerics: results whose summation order the reference's
+ *    own source fixes (Euclidean SimCross forward/backward, PairRankLoss
+ *    per-element terms and gradients) are BIT-IDENTICAL to the reference CPU
+ *    code.  Results that pass through CBLAS in the reference (cosine,
+ *    bilinear, SimMatrix) or a long scalar sum (the loss value) agree to
+ *    1e-5 relative.
+ *  - dist_mode: 0 cosine, 1 Euclidean 1/(1+||q-a||), 2 bilinear q W a^T
+ *    (src/caffe/proto/caffe.proto:471-477; default 1).
+ */
+#ifndef MMS_H_
+#define MMS_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMS_VERSION 100 /* 0.1.0 */
+
+enum {
+  MMS_OK = 0,
+  MMS_ERR_INVALID_ARG = 1,   /* null pointer, negative size, unknown mode     */
+  MMS_ERR_UNSUPPORTED = 2,   /* valid request this build cannot run           */
+  MMS_ERR_WORKSPACE = 3,     /* workspace missing or too small                */
+  MMS_ERR_LAUNCH = 4         /* hipGetLastError() != hipSuccess after launch  */
+};
+
+int mms_version(void);
+const char* mms_error_string(int code);
+
+/* ------------------------------------------------------------------------- *
+ * SimCross  (q (N,W1,D), a (N,W2,D) -> top (N, M|1, W1, W2))
+ * ------------------------------------------------------------------------- */
+
+/* Replaces SimCrossLayer<float>::Forward_cpu / Forward_gpu
+ *   src/caffe/layers/sim_cross_layer.cpp:83-163, sim_cross_layer.cu:128-194.
+ * W (M,D,D) and bias (M,W1,W2) are read for dist_mode 2 only (bias may be NULL
+ * = bias_term false).  norm0 (N,W1) / norm1 (N,W2) are the layer's
+ * data{0,1}_norm_ blobs: written for dist_mode 0 (they hold the NORM, like the
+ * CPU code, :118,:126 -- not the squared norm the reference .cu caches),
+ * ignored otherwise.  M is mesure_count (dist_mode 2) and must be 1 otherwise.
+ * workspace: mms_simcross_workspace_bytes(...) bytes of device scratch. */
+int mms_simcross_forward_f32(int dist_mode, int N, int W1, int W2, int D, int M,
+                             const float* q, const float* a, const float* W,
+                             const float* bias, float* top, float* norm0,
+                             float* norm1, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* Replaces SimCrossLayer<float>::Backward_cpu / Backward_gpu
+ *   src/caffe/layers/sim_cross_layer.cpp:166-307, sim_cross_layer.cu:197-243.
+ * Reference-visible behaviour kept: dq and da are ALWAYS overwritten (zeroed
+ * first, :176-177); if neither propagate_down flag is set they stay zero, if
+ * either is set BOTH are computed (:201).  dist_mode 2: dW (M,D,D) is
+ * overwritten (the reference zeroes W.diff itself, :256); dbias (M,W1,W2) is
+ * ACCUMULATED into (:301-304) when bias_term != 0. */
+int mms_simcross_backward_f32(int dist_mode, int N, int W1, int W2, int D, int M,
+                              const float* q, const float* a, const float* W,
+                              int bias_term, const float* top,
+                              const float* top_diff, const float* norm0,
+                              const float* norm1, int propagate_down0,
+                              int propagate_down1, float* dq, float* da,
+                              float* dW, float* dbias, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
+/* Forward immediately followed by Backward with a top_diff known up front
+ * (the `caffe time` loop, tools/caffe.cpp:349-361, and any net whose loss
+ * gradient does not depend on this layer's output), in ONE launch for
+ * dist_mode 0/1: q and a are read once, top/dq/da written once.  Results are
+ * identical to the two calls above.  dist_mode 2 runs the two passes
+ * back to back on `stream`. */
+int mms_simcross_forward_backward_f32(int dist_mode, int N, int W1, int W2,
+                                      int D, int M, const float* q,
+                                      const float* a, const float* W,
+                                      const float* bias, const float* top_diff,
+                                      float* top, float* norm0, float* norm1,
+                                      float* dq, float* da, float* dW,
+                                      float* dbias, void* workspace,
+                                      size_t workspace_bytes, void* stream);
+
+/* Device scratch needed by the three calls above (0 is possible). */
+size_t mms_simcross_workspace_bytes(int dist_mode, int N, int W1, int W2, int D,
+                                    int M);
+
+/* ------------------------------------------------------------------------- *
+ * SimMatrix  (q (N,K1), a (N,K2), W (K1,K2) -> top (N,1), s_i = q_i^T W a_i)
+ * ------------------------------------------------------------------------- */
+
+/* Replaces SimMatrixLayer<float>::Forward_cpu / Forward_gpu
+ *   src/caffe/layers/sim_matrix_layer.cpp:53-65, sim_matrix_layer.cu:21-41.
+ * qw_scratch (N,K2) receives Q*W.  The reference uses bottom[1]'s diff buffer
+ * for it (:58); pass a_blob->mutable_gpu_diff() to reproduce that side effect. */
+int mms_simmatrix_forward_f32(int N, int K1, int K2, const float* q,
+                              const float* a, const float* W, float* top,
+                              float* qw_scratch, void* stream);
+
+/* Replaces SimMatrixLayer<float>::Backward_cpu / Backward_gpu
+ *   src/caffe/layers/sim_matrix_layer.cpp:68-95, sim_matrix_layer.cu:43-46.
+ * dW (K1,K2) is ACCUMULATED into when param_propagate_down (:73-80);
+ * dq / da are overwritten when their propagate_down flag is set (:81-93) and
+ * left untouched otherwise. */
+int mms_simmatrix_backward_f32(int N, int K1, int K2, const float* q,
+                               const float* a, const float* W,
+                               const float* top_diff, int param_propagate_down,
+                               int propagate_down0, int propagate_down1,
+                               float* dq, float* da, float* dW, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
+size_t mms_simmatrix_workspace_bytes(int N, int K1, int K2);
+
+/* ------------------------------------------------------------------------- *
+ * PairRankLoss  (a, b, y of `count` = N*C elements -> scalar loss)
+ * ------------------------------------------------------------------------- */
+
+/* Replaces PairRankLossLayer<float>::Forward_cpu / Forward_gpu
+ *   src/caffe/layers/pair_rank_loss_layer.cpp:26-52, pair_rank_loss_layer.cu:10-43.
+ * ordered / similar are the layer's cached ordered_diff_ / similar_diff_ blobs
+ * (count floats each, outputs).  loss is ONE device float. */
+int mms_pairrank_forward_f32(int count, float margin, const float* a,
+                             const float* b, const float* y, float* ordered,
+                             float* similar, float* loss, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* Replaces PairRankLossLayer<float>::Backward_cpu / Backward_gpu
+ *   src/caffe/layers/pair_rank_loss_layer.cpp:55-84, pair_rank_loss_layer.cu:45-83.
+ * top_diff = top[0]->cpu_diff()[0] (the loss weight).  Uses the CPU code's
+ * strict `ordered > 0` (:76), not the .cu's `>=`.  da / db are overwritten
+ * when their flag is set.  (propagate_down[2] is a LOG(FATAL) in the
+ * reference and is rejected one level up, in the Layer mirror.) */
+int mms_pairrank_backward_f32(int count, float top_diff, const float* y,
+                              const float* ordered, const float* similar,
+                              int propagate_down0, int propagate_down1,
+                              float* da, float* db, void* stream);
+
+size_t mms_pairrank_workspace_bytes(int count);
+
+/* ------------------------------------------------------------------------- *
+ * Fused training step of the metric-learning inner loop (one launch):
+ *   s_pos = SimCross_euclid(q, a_pos), s_neg = SimCross_euclid(q, a_neg)   (N,1,1,1)
+ *   loss  = PairRankLoss(s_pos, s_neg, y)                 (margin, loss_weight)
+ *   backward through PairRankLoss and both SimCross layers:
+ *   dq = dq(from pos) + dq(from neg)  (Caffe's Split layer sum), da_pos, da_neg.
+ * Equivalent net: two SimCross layers sharing bottom q (sim_cross_layer.cpp)
+ * feeding PairRankLoss (pair_rank_loss_layer.cpp), geometry W1 = W2 = 1.
+ * Outputs equal the layer-by-layer result (loss to 1e-5, the rest bitwise).
+ * loss_partials: mms_triplet_workspace_bytes(N) bytes of device scratch.
+ * ------------------------------------------------------------------------- */
+int mms_triplet_euclid_step_f32(int N, int D, float margin, float loss_weight,
+                                const float* q, const float* a_pos,
+                                const float* a_neg, const float* y,
+                                float* s_pos, float* s_neg, float* loss,
+                                float* dq, float* da_pos, float* da_neg,
+                                void* workspace, size_t workspace_bytes,
+                                void* stream);
+
+size_t mms_triplet_workspace_bytes(int N);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMS_H_ */

@@ -1,0 +1,84 @@
+"""Build libmms_hip.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU.  Flags that matter for parity:
+  -ffp-contract=off   the reference CPU build has no FMA contraction; mul and
+                      add must round separately for bit-exact Euclidean paths.
+  -fhip-fp32-correctly-rounded-divide-sqrt   IEEE sqrt / divide (hipcc default,
+                      stated explicitly because the parity tests rely on it).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmms_hip.so")
+LAYER_LIB = os.path.join(HERE, "libmms_caffe.so")
+
+HIP_SOURCES = ["mms_abi.hip", "simcross_elementwise.hip", "bilinear.hip", "pairrank.hip"]
+HIP_HEADERS = ["mms_common.h"]
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-fno-fast-math", "-Wall", "-Wno-unused-function",
+]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP library cannot be built (no fallback exists)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, f) for f in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, f) for f in HIP_HEADERS] + [
+        os.path.join(ROOT, "include", "mms.h"), os.path.abspath(__file__)]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC] + srcs + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_layers(force=False, verbose=False):
+    """C++ mirror of the Caffe Layer/Blob API on top of the C ABI."""
+    src = os.path.join(CSRC, "caffe_layers.cpp")
+    if not os.path.exists(src):
+        return None
+    deps = [src, os.path.join(CSRC, "caffe_api.hpp"), os.path.join(ROOT, "include", "mms.h"),
+            os.path.join(ROOT, "include", "mms_layer.h"), LIB, os.path.abspath(__file__)]
+    deps = [d for d in deps if os.path.exists(d)]
+    if not force and not _stale(LAYER_LIB, deps):
+        return LAYER_LIB
+    cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "--offload-arch=gfx950",
+           "-Wall", "-I", os.path.join(ROOT, "include"), "-I", CSRC, src, "-o", LAYER_LIB,
+           "-L", HERE, "-lmms_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LAYER_LIB
+
+
+def build_all(force=False, verbose=False):
+    out = [build_hip(force, verbose)]
+    l = build_layers(force, verbose)
+    if l:
+        out.append(l)
+    return out
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

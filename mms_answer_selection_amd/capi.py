@@ -1,0 +1,189 @@
+"""ctypes binding of libmms_hip.so (include/mms.h) for torch device tensors.
+
+torch is plumbing here: it owns device memory and the HIP stream; every
+computation goes through the C ABI.  There is NO fallback: if the library is
+missing or a tensor is not on the GPU the call raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmms_hip.so")
+
+MMS_OK = 0
+_lib = None
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+_SIGNATURES = {
+    "mms_version": (C.c_int, []),
+    "mms_error_string": (C.c_char_p, [_i]),
+    "mms_simcross_workspace_bytes": (_sz, [_i] * 6),
+    "mms_simcross_forward_f32": (_i, [_i] * 6 + [_vp] * 8 + [_sz, _vp]),
+    "mms_simcross_backward_f32": (_i, [_i] * 6 + [_vp] * 3 + [_i] + [_vp] * 4 + [_i, _i] + [_vp] * 5 + [_sz, _vp]),
+    "mms_simcross_forward_backward_f32": (_i, [_i] * 6 + [_vp] * 13 + [_sz, _vp]),
+    "mms_simmatrix_workspace_bytes": (_sz, [_i] * 3),
+    "mms_simmatrix_forward_f32": (_i, [_i] * 3 + [_vp] * 6),
+    "mms_simmatrix_backward_f32": (_i, [_i] * 3 + [_vp] * 4 + [_i] * 3 + [_vp] * 4 + [_sz, _vp]),
+    "mms_pairrank_workspace_bytes": (_sz, [_i]),
+    "mms_pairrank_forward_f32": (_i, [_i, _f] + [_vp] * 7 + [_sz, _vp]),
+    "mms_pairrank_backward_f32": (_i, [_i, _f] + [_vp] * 3 + [_i, _i] + [_vp] * 3),
+    "mms_triplet_workspace_bytes": (_sz, [_i]),
+    "mms_triplet_euclid_step_f32": (_i, [_i, _i, _f, _f] + [_vp] * 11 + [_sz, _vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class MMSError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded C-ABI library; raises (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MMSError(
+                "libmms_hip.so is not built (%s). Run `python -m mms_answer_selection_amd.build` "
+                "or __graft_entry__.build(); there is no CPU fallback." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the header and library diverge
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != MMS_OK:
+        raise MMSError("%s failed: %s (code %d)" % (what, lib().mms_error_string(rc).decode(), rc))
+
+
+def _ptr(t, name, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise MMSError("%s: tensor required" % name)
+    if not t.is_cuda:
+        raise MMSError("%s must live in GPU memory (got %s); the HIP path has no CPU fallback"
+                       % (name, t.device))
+    if t.dtype != torch.float32:
+        raise MMSError("%s must be float32 (got %s)" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise MMSError("%s must be contiguous" % name)
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Workspace:
+    """Grow-only device scratch, owned by the caller of the C ABI (a layer)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if nbytes == 0:
+            return None, 0
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self.buf.data_ptr(), self.buf.numel()
+
+
+_default_ws = Workspace()
+
+
+def simcross_workspace_bytes(mode, N, W1, W2, D, M):
+    return lib().mms_simcross_workspace_bytes(mode, N, W1, W2, D, M)
+
+
+def simcross_forward(mode, q, a, top, W=None, bias=None, norm0=None, norm1=None, ws=None):
+    N, W1, D = q.shape
+    W2 = a.shape[1]
+    M = W.shape[0] if mode == 2 else 1
+    wsp, wsb = (ws or _default_ws).get(simcross_workspace_bytes(mode, N, W1, W2, D, M), q.device)
+    check(lib().mms_simcross_forward_f32(
+        mode, N, W1, W2, D, M, _ptr(q, "q"), _ptr(a, "a"), _ptr(W, "W", True),
+        _ptr(bias, "bias", True), _ptr(top, "top"), _ptr(norm0, "norm0", True),
+        _ptr(norm1, "norm1", True), wsp, wsb, _stream()), "mms_simcross_forward_f32")
+
+
+def simcross_backward(mode, q, a, top, top_diff, dq, da, W=None, bias_term=False, norm0=None,
+                      norm1=None, dW=None, dbias=None, propagate_down=(True, True), ws=None):
+    N, W1, D = q.shape
+    W2 = a.shape[1]
+    M = W.shape[0] if mode == 2 else 1
+    wsp, wsb = (ws or _default_ws).get(simcross_workspace_bytes(mode, N, W1, W2, D, M), q.device)
+    check(lib().mms_simcross_backward_f32(
+        mode, N, W1, W2, D, M, _ptr(q, "q"), _ptr(a, "a"), _ptr(W, "W", True), int(bool(bias_term)),
+        _ptr(top, "top"), _ptr(top_diff, "top_diff"), _ptr(norm0, "norm0", True),
+        _ptr(norm1, "norm1", True), int(bool(propagate_down[0])), int(bool(propagate_down[1])),
+        _ptr(dq, "dq"), _ptr(da, "da"), _ptr(dW, "dW", True), _ptr(dbias, "dbias", True),
+        wsp, wsb, _stream()), "mms_simcross_backward_f32")
+
+
+def simcross_forward_backward(mode, q, a, top_diff, top, dq, da, W=None, bias=None, norm0=None,
+                              norm1=None, dW=None, dbias=None, ws=None):
+    N, W1, D = q.shape
+    W2 = a.shape[1]
+    M = W.shape[0] if mode == 2 else 1
+    wsp, wsb = (ws or _default_ws).get(simcross_workspace_bytes(mode, N, W1, W2, D, M), q.device)
+    check(lib().mms_simcross_forward_backward_f32(
+        mode, N, W1, W2, D, M, _ptr(q, "q"), _ptr(a, "a"), _ptr(W, "W", True),
+        _ptr(bias, "bias", True), _ptr(top_diff, "top_diff"), _ptr(top, "top"),
+        _ptr(norm0, "norm0", True), _ptr(norm1, "norm1", True), _ptr(dq, "dq"), _ptr(da, "da"),
+        _ptr(dW, "dW", True), _ptr(dbias, "dbias", True), wsp, wsb, _stream()),
+        "mms_simcross_forward_backward_f32")
+
+
+def simmatrix_forward(q, a, W, top, qw_scratch):
+    N = q.shape[0]
+    K1, K2 = W.shape
+    check(lib().mms_simmatrix_forward_f32(
+        N, K1, K2, _ptr(q, "q"), _ptr(a, "a"), _ptr(W, "W"), _ptr(top, "top"),
+        _ptr(qw_scratch, "qw_scratch"), _stream()), "mms_simmatrix_forward_f32")
+
+
+def simmatrix_backward(q, a, W, top_diff, dq, da, dW, param_propagate_down=True,
+                       propagate_down=(True, True), ws=None):
+    N = q.shape[0]
+    K1, K2 = W.shape
+    wsp, wsb = (ws or _default_ws).get(lib().mms_simmatrix_workspace_bytes(N, K1, K2), q.device)
+    check(lib().mms_simmatrix_backward_f32(
+        N, K1, K2, _ptr(q, "q"), _ptr(a, "a"), _ptr(W, "W"), _ptr(top_diff, "top_diff"),
+        int(bool(param_propagate_down)), int(bool(propagate_down[0])), int(bool(propagate_down[1])),
+        _ptr(dq, "dq", True), _ptr(da, "da", True), _ptr(dW, "dW", True), wsp, wsb, _stream()),
+        "mms_simmatrix_backward_f32")
+
+
+def pairrank_forward(a, b, y, ordered, similar, loss, margin=1.0, ws=None):
+    count = a.numel()
+    wsp, wsb = (ws or _default_ws).get(lib().mms_pairrank_workspace_bytes(count), a.device)
+    check(lib().mms_pairrank_forward_f32(
+        count, float(margin), _ptr(a, "a"), _ptr(b, "b"), _ptr(y, "y"), _ptr(ordered, "ordered"),
+        _ptr(similar, "similar"), _ptr(loss, "loss"), wsp, wsb, _stream()),
+        "mms_pairrank_forward_f32")
+
+
+def pairrank_backward(y, ordered, similar, da, db, top_diff=1.0, propagate_down=(True, True)):
+    check(lib().mms_pairrank_backward_f32(
+        y.numel(), float(top_diff), _ptr(y, "y"), _ptr(ordered, "ordered"),
+        _ptr(similar, "similar"), int(bool(propagate_down[0])), int(bool(propagate_down[1])),
+        _ptr(da, "da", True), _ptr(db, "db", True), _stream()), "mms_pairrank_backward_f32")
+
+
+def triplet_euclid_step(q, a_pos, a_neg, y, s_pos, s_neg, loss, dq, da_pos, da_neg, margin=1.0,
+                        loss_weight=1.0, ws=None):
+    N, D = q.shape[0], q.shape[-1]
+    wsp, wsb = (ws or _default_ws).get(lib().mms_triplet_workspace_bytes(N), q.device)
+    check(lib().mms_triplet_euclid_step_f32(
+        N, D, float(margin), float(loss_weight), _ptr(q, "q"), _ptr(a_pos, "a_pos"),
+        _ptr(a_neg, "a_neg"), _ptr(y, "y"), _ptr(s_pos, "s_pos"), _ptr(s_neg, "s_neg"),
+        _ptr(loss, "loss"), _ptr(dq, "dq"), _ptr(da_pos, "da_pos"), _ptr(da_neg, "da_neg"),
+        wsp, wsb, _stream()), "mms_triplet_euclid_step_f32")

@@ -1,0 +1,419 @@
+// csrc/bilinear.hip -- the learned-metric (bilinear W) paths on the gfx950
+// matrix cores: SimCross dist_mode 2 and SimMatrix, forward and backward.
+//
+// Reference:
+//   SimCross mode 2 fwd  sim_cross_layer.cpp:140-161   T[n,m] = Q_n W_m A_n^T (+ bias_m)
+//   SimCross mode 2 bwd  sim_cross_layer.cpp:251-305   dW_m = sum_n Q_n^T dT_nm A_n (W.diff zeroed),
+//                         dQ_n += dT_nm (W_m A_n^T)^T, dA_n += dT_nm^T (Q_n W_m), dbias += dT_n
+//   SimMatrix fwd/bwd    sim_matrix_layer.cpp:53-65, 68-95
+// The reference issues 2 (fwd) / 6 (bwd) small cblas_sgemm calls per (pair,
+// measure) on the host -- even in GPU mode (sim_cross_layer.cu:187-189,
+// 240-242).  Here the contraction over the embedding dimension is regrouped so
+// that all pairs share ONE large GEMM per weight matrix:
+//   fwd:  tmp_m = Q_all W_m            (N*W1 x D x D)    then T = tmp A^T per pair
+//   bwd:  U_nm = dT_nm A_n , V_nm = dT_nm^T Q_n           (small, per pair)
+//         dQ_all = sum_m U_m W_m^T , dA_all = sum_m V_m W_m   (N*W x D x D)
+//         dW_m   = Q_all^T U_m                              (D x D x N*W1, split-K)
+// Algebraically identical to the reference's grouping; fp32 rounding differs
+// (as it does between BLAS libraries), tests hold it to 1e-5.
+//
+// All products use v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate, each MFMA
+// bit-equal to a k-ordered fmaf chain -- no reduced-precision path.
+// Deterministic: split-K partial slabs are summed in a fixed order, no atomics.
+#include "mms_common.h"
+
+namespace mms {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  int M, N, K;
+  const float* A; long long a_rs, a_cs;  // A(i,k) = A[i*a_rs + k*a_cs]
+  const float* B; long long b_rs, b_cs;  // B(k,j) = B[k*b_rs + j*b_cs]
+  float* C; long long ldc;               // C(i,j) = C[i*ldc + j]
+  // blockIdx.z = (b0 * nb1 + b1) * ksplit + ks
+  int nb1, ksplit, kchunk;
+  long long a_b0, a_b1, b_b0, b_b1, c_b0, c_b1, c_ks;
+  const float* rowscale; long long rs_b0;  // optional C(i,j) = rowscale[i] * acc
+  const float* addend; long long ad_b1;    // optional C(i,j) += addend[i*ldc + j]
+  int beta_one;                            // C = result + C
+  int a_ifast, b_jfast;                    // which index is contiguous in memory
+};
+
+constexpr int BM = 128, BN = 64, BK = 16;
+constexpr int LSA = BM + 4, LSB = BN + 4;
+
+// 256 threads = 4 waves stacked along M; wave w owns rows [32w,32w+32) x 64 cols
+// = two 32x32 MFMA tiles.  LDS tiles are k-major so a fragment read is 32
+// consecutive floats per half-wave (conflict-free).
+__global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
+  __shared__ float As[BK * LSA];
+  __shared__ float Bs[BK * LSB];
+
+  const int z = blockIdx.z;
+  const int ks = z % g.ksplit;
+  const int b1 = (z / g.ksplit) % g.nb1;
+  const int b0 = (z / g.ksplit) / g.nb1;
+  const float* A = g.A + b0 * g.a_b0 + b1 * g.a_b1;
+  const float* B = g.B + b0 * g.b_b0 + b1 * g.b_b1;
+  float* C = g.C + b0 * g.c_b0 + b1 * g.c_b1 + ks * g.c_ks;
+  const int kbeg = ks * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+
+  // staging registers: A tile 128x16 -> 8 per thread, B tile 16x64 -> 4 per thread
+  float ra[8], rb[4];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      int i, k;
+      if (g.a_ifast) { i = t & 127; k = (t >> 7) + 2 * p; }
+      else { k = t & 15; i = (t >> 4) + 16 * p; }
+      const int gi = i0 + i, gk = k0 + k;
+      ra[p] = (gi < g.M && gk < kend) ? A[gi * g.a_rs + gk * g.a_cs] : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int j, k;
+      if (g.b_jfast) { j = t & 63; k = (t >> 6) + 4 * p; }
+      else { k = t & 15; j = (t >> 4) + 16 * p; }
+      const int gj = j0 + j, gk = k0 + k;
+      rb[p] = (gj < g.N && gk < kend) ? B[gk * g.b_rs + gj * g.b_cs] : 0.f;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      int i, k;
+      if (g.a_ifast) { i = t & 127; k = (t >> 7) + 2 * p; }
+      else { k = t & 15; i = (t >> 4) + 16 * p; }
+      As[k * LSA + i] = ra[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int j, k;
+      if (g.b_jfast) { j = t & 63; k = (t >> 6) + 4 * p; }
+      else { k = t & 15; j = (t >> 4) + 16 * p; }
+      Bs[k * LSB + j] = rb[p];
+    }
+  };
+
+  v16f acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+  if (kbeg < kend) {
+    load_tiles(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      __syncthreads();
+      store_tiles();
+      __syncthreads();
+      if (k0 + BK < kend) load_tiles(k0 + BK);
+      const int ar = wave * 32 + (lane & 31), kh = lane >> 5;
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        const float av = As[(kk + kh) * LSA + ar];
+        const float bv0 = Bs[(kk + kh) * LSB + (lane & 31)];
+        const float bv1 = Bs[(kk + kh) * LSB + 32 + (lane & 31)];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv1, acc1, 0, 0, 0);
+      }
+    }
+  }
+
+  // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const float* rs = g.rowscale ? g.rowscale + b0 * g.rs_b0 : nullptr;
+  const float* ad = g.addend ? g.addend + b1 * g.ad_b1 : nullptr;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gi = i0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (gi >= g.M) continue;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int gj = j0 + 32 * h + (lane & 31);
+      if (gj >= g.N) continue;
+      float v = h ? acc1[r] : acc0[r];
+      if (rs) v = rs[gi] * v;
+      if (ad) v = ad[gi * g.ldc + gj] + v;
+      float* c = C + gi * g.ldc + gj;
+      if (g.beta_one) v = v + *c;
+      *c = v;
+    }
+  }
+}
+
+static GemmArgs gemm_args(int M, int N, int K, const float* A, long long a_rs, long long a_cs,
+                          const float* B, long long b_rs, long long b_cs, float* C,
+                          long long ldc) {
+  GemmArgs g{};
+  g.M = M; g.N = N; g.K = K;
+  g.A = A; g.a_rs = a_rs; g.a_cs = a_cs;
+  g.B = B; g.b_rs = b_rs; g.b_cs = b_cs;
+  g.C = C; g.ldc = ldc;
+  g.nb1 = 1; g.ksplit = 1; g.kchunk = K;
+  g.a_ifast = (a_rs == 1 && a_cs != 1);
+  g.b_jfast = (b_cs == 1);
+  return g;
+}
+
+static void gemm_launch(const GemmArgs& g0, int nb0, hipStream_t s) {
+  // gridDim.z <= 65535: slice the outer batch when (pairs x measures x splits) is larger.
+  const int per_b0 = g0.nb1 * g0.ksplit;
+  const int max_b0 = per_b0 > 65535 ? 1 : 65535 / per_b0;
+  for (int b = 0; b < nb0; b += max_b0) {
+    const int nb = (nb0 - b) < max_b0 ? (nb0 - b) : max_b0;
+    GemmArgs g = g0;
+    g.A += (long long)b * g.a_b0;
+    g.B += (long long)b * g.b_b0;
+    g.C += (long long)b * g.c_b0;
+    if (g.rowscale) g.rowscale += (long long)b * g.rs_b0;
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, nb * per_b0);
+    hipLaunchKernelGGL(gemm32_kernel, grid, dim3(256), 0, s, g);
+  }
+}
+
+// out[e] (= or +=) sum_s part[s*n + e], s ascending.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part,
+                                                            int splits, long long n,
+                                                            float* __restrict__ out,
+                                                            int accumulate) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(long long)k * n + e];
+    out[e] = accumulate ? out[e] + s : s;
+  }
+}
+
+// out[r][c] = scale[r] * x[r][c]
+__global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ scale,
+                                                       float* __restrict__ out, long long rows,
+                                                       int cols) {
+  const long long n = rows * cols;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride)
+    out[e] = scale[e / cols] * x[e];
+}
+
+// top[r] = dot(x[r], y[r]) (+ bias)  -- one wave per row, fixed butterfly.
+// top index = r*top_stride ; bias is a single value (may be null).
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x,
+                                                     const float* __restrict__ y,
+                                                     const float* __restrict__ bias,
+                                                     float* __restrict__ top, long long rows,
+                                                     int cols, long long top_stride) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + r * cols;
+  const float* yr = y + r * cols;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += xr[c] * yr[c];
+  s = wave_sum(s);
+  if (lane == 0) top[r * top_stride] = bias ? (*bias + s) : s;
+}
+
+// dbias[e] = dT[n][e] + dbias[e] for n ascending (sim_cross_layer.cpp:301-304:
+// same order, bit-exact).  One thread per e.
+__global__ __launch_bounds__(256) void dbias_kernel(const float* __restrict__ top_diff, int N,
+                                                    int per_n, float* __restrict__ dbias) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= per_n) return;
+  float s = dbias[e];
+  for (int n = 0; n < N; ++n) s = top_diff[(size_t)n * per_n + e] + s;
+  dbias[e] = s;
+}
+
+static unsigned ew_blocks(long long n) {
+  long long b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+static int pick_ksplit(int Mt, int Nt, int K, int* kchunk) {
+  const long long tiles = (long long)((Mt + BM - 1) / BM) * ((Nt + BN - 1) / BN);
+  long long want = (1024 + tiles - 1) / tiles;  // aim for ~4 workgroups per CU
+  long long maxs = (K + 4 * BK - 1) / (4 * BK); // at least 64 of K per split
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  int chunk = (int)((K + want - 1) / want);
+  chunk = (chunk + BK - 1) / BK * BK;
+  *kchunk = chunk;
+  return (K + chunk - 1) / chunk;
+}
+
+// ------------------------------ workspace layout ----------------------------
+struct BilinearWs {
+  size_t u_off, v_off, part_off, total;
+  int ksplit, kchunk;
+};
+static BilinearWs bilinear_ws(int N, int W1, int W2, int D, int M) {
+  BilinearWs w{};
+  const size_t u = (size_t)M * N * W1 * D, v = (size_t)M * N * W2 * D;
+  w.ksplit = pick_ksplit(D, D, N * W1, &w.kchunk);
+  w.u_off = 0;
+  w.v_off = round_up(u * sizeof(float), 256);
+  w.part_off = w.v_off + round_up(v * sizeof(float), 256);
+  w.total = w.part_off + round_up((size_t)w.ksplit * M * D * D * sizeof(float), 256);
+  return w;
+}
+size_t bilinear_workspace_bytes(int N, int W1, int W2, int D, int M) {
+  return bilinear_ws(N, W1, W2, D, M).total;
+}
+
+int bilinear_forward(int N, int W1, int W2, int D, int M, const float* q, const float* a,
+                     const float* W, const float* bias, float* top, void* ws, size_t ws_bytes,
+                     hipStream_t s) {
+  const BilinearWs lay = bilinear_ws(N, W1, W2, D, M);
+  if (!ws || ws_bytes < lay.total) return MMS_ERR_WORKSPACE;
+  float* tmp = reinterpret_cast<float*>(static_cast<char*>(ws) + lay.u_off);
+  const long long R = (long long)N * W1;
+  // tmp[m] = Q_all W_m   (:148-149, batched over all pairs)
+  {
+    GemmArgs g = gemm_args((int)R, D, D, q, D, 1, W, D, 1, tmp, D);
+    g.nb1 = M; g.b_b1 = (long long)D * D; g.c_b1 = R * D;
+    gemm_launch(g, 1, s);
+  }
+  if (W1 == 1 && W2 == 1) {
+    // T[n,m] = tmp[m][n] . a[n] (+ bias[m])   (:151-158)
+    for (int m = 0; m < M; ++m)
+      hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s,
+                         tmp + (size_t)m * R * D, a, bias ? bias + m : nullptr, top + m,
+                         (long long)N, D, (long long)M);
+  } else {
+    // T[n,m] = tmp[m][n] A_n^T (+ bias_m), batched over (n, m)
+    GemmArgs g = gemm_args(W1, W2, D, tmp, D, 1, a, 1, D, top, W2);
+    g.nb1 = M;
+    g.a_b0 = (long long)W1 * D; g.a_b1 = R * D;
+    g.b_b0 = (long long)W2 * D; g.b_b1 = 0;
+    g.c_b0 = (long long)M * W1 * W2; g.c_b1 = (long long)W1 * W2;
+    g.addend = bias; g.ad_b1 = (long long)W1 * W2;
+    gemm_launch(g, N, s);
+  }
+  return launch_status();
+}
+
+int bilinear_backward(int N, int W1, int W2, int D, int M, const float* q, const float* a,
+                      const float* W, int bias_term, const float* top_diff, float* dq, float* da,
+                      float* dW, float* dbias, void* ws, size_t ws_bytes, hipStream_t s) {
+  const BilinearWs lay = bilinear_ws(N, W1, W2, D, M);
+  if (!ws || ws_bytes < lay.total) return MMS_ERR_WORKSPACE;
+  char* base = static_cast<char*>(ws);
+  float* U = reinterpret_cast<float*>(base + lay.u_off);     // [M][N*W1][D]
+  float* V = reinterpret_cast<float*>(base + lay.v_off);     // [M][N*W2][D]
+  float* part = reinterpret_cast<float*>(base + lay.part_off);
+  const long long R1 = (long long)N * W1, R2 = (long long)N * W2;
+
+  // U_nm = dT_nm A_n  (W1 x D x W2) ;  V_nm = dT_nm^T Q_n  (W2 x D x W1)
+  if (W1 == 1 && W2 == 1 && M == 1) {
+    hipLaunchKernelGGL(rowscale_kernel, dim3(ew_blocks(R2 * D)), dim3(256), 0, s, a, top_diff, U,
+                       R2, D);
+    hipLaunchKernelGGL(rowscale_kernel, dim3(ew_blocks(R1 * D)), dim3(256), 0, s, q, top_diff, V,
+                       R1, D);
+  } else {
+    GemmArgs gu = gemm_args(W1, D, W2, top_diff, W2, 1, a, D, 1, U, D);
+    gu.nb1 = M;
+    gu.a_b0 = (long long)M * W1 * W2; gu.a_b1 = (long long)W1 * W2;
+    gu.b_b0 = (long long)W2 * D; gu.b_b1 = 0;
+    gu.c_b0 = (long long)W1 * D; gu.c_b1 = R1 * D;
+    gemm_launch(gu, N, s);
+    GemmArgs gv = gemm_args(W2, D, W1, top_diff, 1, W2, q, D, 1, V, D);
+    gv.nb1 = M;
+    gv.a_b0 = (long long)M * W1 * W2; gv.a_b1 = (long long)W1 * W2;
+    gv.b_b0 = (long long)W1 * D; gv.b_b1 = 0;
+    gv.c_b0 = (long long)W2 * D; gv.c_b1 = R2 * D;
+    gemm_launch(gv, N, s);
+  }
+  // dQ_all = sum_m U_m W_m^T ; dA_all = sum_m V_m W_m   (:291-299; m = 0 overwrites,
+  // which also realises the unconditional zeroing of :176-177)
+  for (int m = 0; m < M; ++m) {
+    const float* Wm = W + (size_t)m * D * D;
+    GemmArgs g1 = gemm_args((int)R1, D, D, U + (size_t)m * R1 * D, D, 1, Wm, 1, D, dq, D);
+    g1.beta_one = m > 0;
+    gemm_launch(g1, 1, s);
+    GemmArgs g2 = gemm_args((int)R2, D, D, V + (size_t)m * R2 * D, D, 1, Wm, D, 1, da, D);
+    g2.beta_one = m > 0;
+    gemm_launch(g2, 1, s);
+  }
+  // dW_m = Q_all^T U_m  (:286-289), K = N*W1 split across workgroups; W.diff is
+  // overwritten because the reference zeroes it first (:256).
+  {
+    GemmArgs g = gemm_args(D, D, (int)R1, q, 1, D, U, D, 1, part, D);
+    g.nb1 = M; g.b_b1 = R1 * D; g.c_b1 = (long long)D * D;
+    g.ksplit = lay.ksplit; g.kchunk = lay.kchunk; g.c_ks = (long long)M * D * D;
+    gemm_launch(g, 1, s);
+    const long long n = (long long)M * D * D;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, part,
+                       lay.ksplit, n, dW, 0);
+  }
+  if (bias_term) {
+    const int per_n = M * W1 * W2;
+    hipLaunchKernelGGL(dbias_kernel, dim3((per_n + 255) / 256), dim3(256), 0, s, top_diff, N,
+                       per_n, dbias);
+  }
+  return launch_status();
+}
+
+// ---------------------------------- SimMatrix -------------------------------
+struct SimMatrixWs {
+  size_t u_off, part_off, total;
+  int ksplit, kchunk;
+};
+static SimMatrixWs simmatrix_ws(int N, int K1, int K2) {
+  SimMatrixWs w{};
+  w.ksplit = pick_ksplit(K1, K2, N, &w.kchunk);
+  w.u_off = 0;
+  w.part_off = round_up((size_t)N * K2 * sizeof(float), 256);
+  w.total = w.part_off + round_up((size_t)w.ksplit * K1 * K2 * sizeof(float), 256);
+  return w;
+}
+size_t simmatrix_workspace_bytes(int N, int K1, int K2) { return simmatrix_ws(N, K1, K2).total; }
+
+int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, const float* W,
+                      float* top, float* qw, hipStream_t s) {
+  // qw = Q W  (:60-61) ; top_i = a_i . qw_i  (:62-64)
+  GemmArgs g = gemm_args(N, K2, K1, q, K1, 1, W, K2, 1, qw, K2);
+  gemm_launch(g, 1, s);
+  hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a, qw, nullptr,
+                     top, (long long)N, K2, 1LL);
+  return launch_status();
+}
+
+int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, const float* W,
+                       const float* top_diff, int ppd, int pd0, int pd1, float* dq, float* da,
+                       float* dW, void* ws, size_t ws_bytes, hipStream_t s) {
+  const SimMatrixWs lay = simmatrix_ws(N, K1, K2);
+  if (ppd) {
+    if (!ws || ws_bytes < lay.total) return MMS_ERR_WORKSPACE;
+    char* base = static_cast<char*>(ws);
+    float* U = reinterpret_cast<float*>(base + lay.u_off);
+    float* part = reinterpret_cast<float*>(base + lay.part_off);
+    // dW += sum_i dT_i q_i a_i^T = Q^T (diag(dT) A)   (:73-80, accumulating)
+    hipLaunchKernelGGL(rowscale_kernel, dim3(ew_blocks((long long)N * K2)), dim3(256), 0, s, a,
+                       top_diff, U, (long long)N, K2);
+    GemmArgs g = gemm_args(K1, K2, N, q, 1, K1, U, K2, 1, part, K2);
+    g.ksplit = lay.ksplit; g.kchunk = lay.kchunk; g.c_ks = (long long)K1 * K2;
+    gemm_launch(g, 1, s);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks((long long)K1 * K2)), dim3(256), 0, s,
+                       part, lay.ksplit, (long long)K1 * K2, dW, 1);
+  }
+  if (pd0) {
+    // dq_j = dT_j * (W a_j)   (:88, NoTrans, beta 0)
+    GemmArgs g = gemm_args(N, K1, K2, a, K2, 1, W, 1, K2, dq, K1);
+    g.rowscale = top_diff;
+    gemm_launch(g, 1, s);
+  }
+  if (pd1) {
+    // da_j = dT_j * (W^T q_j)   (:88, Trans, beta 0)
+    GemmArgs g = gemm_args(N, K2, K1, q, K1, 1, W, K2, 1, da, K2);
+    g.rowscale = top_diff;
+    gemm_launch(g, 1, s);
+  }
+  return launch_status();
+}
+
+}  // namespace mms

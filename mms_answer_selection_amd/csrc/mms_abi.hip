@@ -1,0 +1,214 @@
+// csrc/mms_abi.hip -- extern "C" entry points declared in include/mms.h:
+// argument validation and dispatch only; kernels live in the sibling files.
+#include "mms_common.h"
+
+namespace mms {
+// simcross_elementwise.hip
+int simcross_elementwise_forward(int mode, int N, int W1, int W2, int D, const float* q,
+                                 const float* a, float* top, float* norm0, float* norm1,
+                                 hipStream_t s);
+int simcross_elementwise_backward(int mode, int N, int W1, int W2, int D, const float* q,
+                                  const float* a, const float* top, const float* top_diff,
+                                  const float* norm0, const float* norm1, float* dq, float* da,
+                                  hipStream_t s);
+int simcross_elementwise_forward_backward(int mode, int N, int W1, int W2, int D, const float* q,
+                                          const float* a, const float* top_diff, float* top,
+                                          float* norm0, float* norm1, float* dq, float* da,
+                                          hipStream_t s);
+// bilinear.hip
+size_t bilinear_workspace_bytes(int N, int W1, int W2, int D, int M);
+int bilinear_forward(int N, int W1, int W2, int D, int M, const float* q, const float* a,
+                     const float* W, const float* bias, float* top, void* ws, size_t ws_bytes,
+                     hipStream_t s);
+int bilinear_backward(int N, int W1, int W2, int D, int M, const float* q, const float* a,
+                      const float* W, int bias_term, const float* top_diff, float* dq, float* da,
+                      float* dW, float* dbias, void* ws, size_t ws_bytes, hipStream_t s);
+size_t simmatrix_workspace_bytes(int N, int K1, int K2);
+int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, const float* W,
+                      float* top, float* qw, hipStream_t s);
+int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, const float* W,
+                       const float* top_diff, int ppd, int pd0, int pd1, float* dq, float* da,
+                       float* dW, void* ws, size_t ws_bytes, hipStream_t s);
+// pairrank.hip
+size_t pairrank_workspace_bytes(int count);
+int pairrank_forward(int count, float margin, const float* a, const float* b, const float* y,
+                     float* ordered, float* similar, float* loss, void* ws, size_t ws_bytes,
+                     hipStream_t s);
+int pairrank_backward(int count, float top_diff, const float* y, const float* ordered,
+                      const float* similar, float* da, float* db, hipStream_t s);
+size_t triplet_workspace_bytes(int N);
+int triplet_euclid_step(int N, int D, float margin, float loss_weight, const float* q,
+                        const float* ap, const float* an, const float* y, float* s_pos,
+                        float* s_neg, float* loss, float* dq, float* dap, float* dan, void* ws,
+                        size_t ws_bytes, hipStream_t s);
+}  // namespace mms
+
+using namespace mms;
+
+namespace {
+bool dims_ok(int mode, int N, int W1, int W2, int D, int M) {
+  if (mode < 0 || mode > 2) return false;
+  if (N < 0 || W1 <= 0 || W2 <= 0 || D <= 0 || M <= 0) return false;
+  if (mode != 2 && M != 1) return false;
+  // element counts must fit the int indexing the reference itself uses
+  const long long lim = 0x7fffffffLL;
+  if ((long long)N * W1 * D > lim || (long long)N * W2 * D > lim ||
+      (long long)N * M * W1 * W2 > lim)
+    return false;
+  return true;
+}
+hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+}  // namespace
+
+extern "C" {
+
+int mms_version(void) { return MMS_VERSION; }
+
+const char* mms_error_string(int code) {
+  switch (code) {
+    case MMS_OK: return "ok";
+    case MMS_ERR_INVALID_ARG: return "invalid argument";
+    case MMS_ERR_UNSUPPORTED: return "unsupported configuration";
+    case MMS_ERR_WORKSPACE: return "workspace missing or too small";
+    case MMS_ERR_LAUNCH: return "HIP kernel launch failed";
+    default: return "unknown error";
+  }
+}
+
+size_t mms_simcross_workspace_bytes(int dist_mode, int N, int W1, int W2, int D, int M) {
+  if (!dims_ok(dist_mode, N, W1, W2, D, M)) return 0;
+  if (dist_mode == 2) return bilinear_workspace_bytes(N, W1, W2, D, M);
+  return 0;
+}
+
+int mms_simcross_forward_f32(int dist_mode, int N, int W1, int W2, int D, int M, const float* q,
+                             const float* a, const float* W, const float* bias, float* top,
+                             float* norm0, float* norm1, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  if (!dims_ok(dist_mode, N, W1, W2, D, M)) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q || !a || !top) return MMS_ERR_INVALID_ARG;
+  if (dist_mode == 0 && (!norm0 || !norm1)) return MMS_ERR_INVALID_ARG;
+  if (dist_mode == 2) {
+    if (!W) return MMS_ERR_INVALID_ARG;
+    return bilinear_forward(N, W1, W2, D, M, q, a, W, bias, top, workspace, workspace_bytes,
+                            as_stream(stream));
+  }
+  return simcross_elementwise_forward(dist_mode, N, W1, W2, D, q, a, top, norm0, norm1,
+                                      as_stream(stream));
+}
+
+int mms_simcross_backward_f32(int dist_mode, int N, int W1, int W2, int D, int M, const float* q,
+                              const float* a, const float* W, int bias_term, const float* top,
+                              const float* top_diff, const float* norm0, const float* norm1,
+                              int propagate_down0, int propagate_down1, float* dq, float* da,
+                              float* dW, float* dbias, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  if (!dims_ok(dist_mode, N, W1, W2, D, M)) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q || !a || !top || !top_diff || !dq || !da) return MMS_ERR_INVALID_ARG;
+  if (dist_mode == 0 && (!norm0 || !norm1)) return MMS_ERR_INVALID_ARG;
+  if (dist_mode == 2 && (!W || !dW || (bias_term && !dbias))) return MMS_ERR_INVALID_ARG;
+  hipStream_t s = as_stream(stream);
+  if (!(propagate_down0 || propagate_down1)) {
+    // sim_cross_layer.cpp:176-177 then nothing else (:201)
+    if (hipMemsetAsync(dq, 0, sizeof(float) * (size_t)N * W1 * D, s) != hipSuccess ||
+        hipMemsetAsync(da, 0, sizeof(float) * (size_t)N * W2 * D, s) != hipSuccess)
+      return MMS_ERR_LAUNCH;
+    return MMS_OK;
+  }
+  if (dist_mode == 2)
+    return bilinear_backward(N, W1, W2, D, M, q, a, W, bias_term, top_diff, dq, da, dW, dbias,
+                             workspace, workspace_bytes, s);
+  return simcross_elementwise_backward(dist_mode, N, W1, W2, D, q, a, top, top_diff, norm0, norm1,
+                                       dq, da, s);
+}
+
+int mms_simcross_forward_backward_f32(int dist_mode, int N, int W1, int W2, int D, int M,
+                                      const float* q, const float* a, const float* W,
+                                      const float* bias, const float* top_diff, float* top,
+                                      float* norm0, float* norm1, float* dq, float* da, float* dW,
+                                      float* dbias, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  if (!dims_ok(dist_mode, N, W1, W2, D, M)) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q || !a || !top || !top_diff || !dq || !da) return MMS_ERR_INVALID_ARG;
+  if (dist_mode == 0 && (!norm0 || !norm1)) return MMS_ERR_INVALID_ARG;
+  if (dist_mode == 2) {
+    int rc = mms_simcross_forward_f32(2, N, W1, W2, D, M, q, a, W, bias, top, norm0, norm1,
+                                      workspace, workspace_bytes, stream);
+    if (rc != MMS_OK) return rc;
+    return mms_simcross_backward_f32(2, N, W1, W2, D, M, q, a, W, bias != nullptr, top, top_diff,
+                                     norm0, norm1, 1, 1, dq, da, dW, dbias, workspace,
+                                     workspace_bytes, stream);
+  }
+  return simcross_elementwise_forward_backward(dist_mode, N, W1, W2, D, q, a, top_diff, top, norm0,
+                                               norm1, dq, da, as_stream(stream));
+}
+
+size_t mms_simmatrix_workspace_bytes(int N, int K1, int K2) {
+  if (N < 0 || K1 <= 0 || K2 <= 0) return 0;
+  return simmatrix_workspace_bytes(N, K1, K2);
+}
+
+int mms_simmatrix_forward_f32(int N, int K1, int K2, const float* q, const float* a,
+                              const float* W, float* top, float* qw_scratch, void* stream) {
+  if (N < 0 || K1 <= 0 || K2 <= 0) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q || !a || !W || !top || !qw_scratch) return MMS_ERR_INVALID_ARG;
+  return simmatrix_forward(N, K1, K2, q, a, W, top, qw_scratch, as_stream(stream));
+}
+
+int mms_simmatrix_backward_f32(int N, int K1, int K2, const float* q, const float* a,
+                               const float* W, const float* top_diff, int param_propagate_down,
+                               int propagate_down0, int propagate_down1, float* dq, float* da,
+                               float* dW, void* workspace, size_t workspace_bytes, void* stream) {
+  if (N < 0 || K1 <= 0 || K2 <= 0) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q || !a || !W || !top_diff) return MMS_ERR_INVALID_ARG;
+  if ((param_propagate_down && !dW) || (propagate_down0 && !dq) || (propagate_down1 && !da))
+    return MMS_ERR_INVALID_ARG;
+  return simmatrix_backward(N, K1, K2, q, a, W, top_diff, param_propagate_down, propagate_down0,
+                            propagate_down1, dq, da, dW, workspace, workspace_bytes,
+                            as_stream(stream));
+}
+
+size_t mms_pairrank_workspace_bytes(int count) {
+  return count > 0 ? pairrank_workspace_bytes(count) : 0;
+}
+
+int mms_pairrank_forward_f32(int count, float margin, const float* a, const float* b,
+                             const float* y, float* ordered, float* similar, float* loss,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  // count == 0 would be 0/0 in the reference (:49); reject instead of writing NaN.
+  if (count <= 0) return MMS_ERR_INVALID_ARG;
+  if (!a || !b || !y || !ordered || !similar || !loss) return MMS_ERR_INVALID_ARG;
+  return pairrank_forward(count, margin, a, b, y, ordered, similar, loss, workspace,
+                          workspace_bytes, as_stream(stream));
+}
+
+int mms_pairrank_backward_f32(int count, float top_diff, const float* y, const float* ordered,
+                              const float* similar, int propagate_down0, int propagate_down1,
+                              float* da, float* db, void* stream) {
+  if (count <= 0) return MMS_ERR_INVALID_ARG;
+  if (!y || !ordered || !similar) return MMS_ERR_INVALID_ARG;
+  if ((propagate_down0 && !da) || (propagate_down1 && !db)) return MMS_ERR_INVALID_ARG;
+  return pairrank_backward(count, top_diff, y, ordered, similar, propagate_down0 ? da : nullptr,
+                           propagate_down1 ? db : nullptr, as_stream(stream));
+}
+
+size_t mms_triplet_workspace_bytes(int N) { return N > 0 ? triplet_workspace_bytes(N) : 0; }
+
+int mms_triplet_euclid_step_f32(int N, int D, float margin, float loss_weight, const float* q,
+                                const float* a_pos, const float* a_neg, const float* y,
+                                float* s_pos, float* s_neg, float* loss, float* dq, float* da_pos,
+                                float* da_neg, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  if (N <= 0 || D <= 0 || (long long)N * D > 0x7fffffffLL) return MMS_ERR_INVALID_ARG;
+  if (!q || !a_pos || !a_neg || !y || !s_pos || !s_neg || !loss || !dq || !da_pos || !da_neg)
+    return MMS_ERR_INVALID_ARG;
+  return triplet_euclid_step(N, D, margin, loss_weight, q, a_pos, a_neg, y, s_pos, s_neg, loss,
+                             dq, da_pos, da_neg, workspace, workspace_bytes, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,557 @@
+// csrc/simcross_elementwise.hip -- SimCross dist_mode 0 (cosine) and 1
+// (Euclidean) forward/backward for gfx950.  HBM-bound: no MFMA here.
+//
+// Reference semantics (all file:line in src/caffe/layers/sim_cross_layer.cpp):
+//   Euclid fwd  :96-111   T = 1/(1+sqrt(sum_d (q-a)^2)), d ascending, fp32.
+//   Euclid bwd  :208-225  tt = dT*T*T*T*(q-a)/(T-1+1e-9) (double divide);
+//                         dq[j,d] = sum_k tt (k ascending from 0),
+//                         da[k,d] = sum_j -tt (j ascending from 0).
+//   Cosine fwd  :112-139  n0,n1 = sqrt(dot) cached; T = dot/n0/n1.
+//   Cosine bwd  :226-250.
+//
+// Two geometries get their own kernels:
+//   "rows"  W1 == W2 == 1 (sentence-vector pairs; BASELINE cfg 2/5): a
+//           workgroup owns ROWS consecutive pairs, streams them with 16-byte
+//           loads into LDS, and ONE lane per pair walks d ascending so the sum
+//           has the reference's order bit for bit.  The forward+backward
+//           fusion keeps q-a in LDS so q and a are read from HBM once.
+//   "cross" general W1 x W2 word grids (TREC-QA 40x40): one wave per
+//           (pair, j-tile, k-tile), q/a d-chunks staged in LDS, an RJ x RK
+//           register tile per lane, d ascending per output.
+//
+// Compiled with -ffp-contract=off: the reference CPU build has no FMA
+// contraction, so mul and add must round separately to match it bitwise.
+#include "mms_common.h"
+
+namespace mms {
+
+// ---- Euclidean backward coefficient (sim_cross_layer.cpp:216-217) ----------
+// numerator  dT*T*T*T*(q-a): float, left to right.
+// divisor    (T - 1) in float, + 1e-9 in double.  Quotient in double -> float.
+__device__ __forceinline__ void euclid_coef(float T, float g, float& c, double& den) {
+  c = g * T * T * T;
+  den = (double)(T - 1.0f) + 1e-9;
+}
+__device__ __forceinline__ float euclid_tt(float c, double den, float diff) {
+  return (float)((double)(c * diff) / den);
+}
+
+// =============================== rows geometry ==============================
+
+// Forward (BWD=false) or forward+backward (BWD=true) for W1=W2=1, Euclidean.
+// LDS: diff[ROWS*D] floats (dynamic) + per-row coefficient slots.
+template <int ROWS, int THREADS, bool VEC4, bool BWD>
+__global__ __launch_bounds__(THREADS) void euclid_rows_kernel(
+    const float* __restrict__ q, const float* __restrict__ a,
+    const float* __restrict__ top_diff, float* __restrict__ top,
+    float* __restrict__ dq, float* __restrict__ da, int N, int D) {
+  extern __shared__ float4 lds_raw[];
+  float* diff = reinterpret_cast<float*>(lds_raw);
+  __shared__ float cs[ROWS];
+  __shared__ double dens[ROWS];
+
+  const int row0 = blockIdx.x * ROWS;
+  const int rows = min(ROWS, N - row0);
+  const size_t base = (size_t)row0 * D;
+  const int total = rows * D;
+
+  if (VEC4) {
+    const float4* q4 = reinterpret_cast<const float4*>(q + base);
+    const float4* a4 = reinterpret_cast<const float4*>(a + base);
+    float4* d4 = reinterpret_cast<float4*>(diff);
+    for (int i = threadIdx.x; i < (total >> 2); i += THREADS) {
+      const float4 x = q4[i], y = a4[i];
+      float4 d;
+      d.x = x.x - y.x; d.y = x.y - y.y; d.z = x.z - y.z; d.w = x.w - y.w;
+      d4[i] = d;
+    }
+  } else {
+    for (int i = threadIdx.x; i < total; i += THREADS) diff[i] = q[base + i] - a[base + i];
+  }
+  __syncthreads();
+
+  // One lane per pair: the reference's d-ascending fp32 chain (:100-106).
+  if (threadIdx.x < rows) {
+    const float* r = diff + threadIdx.x * D;
+    float dist = 0.f;
+    if (VEC4) {
+      const float4* r4 = reinterpret_cast<const float4*>(r);
+#pragma unroll 4
+      for (int d = 0; d < (D >> 2); ++d) {
+        const float4 v = r4[d];
+        dist += v.x * v.x; dist += v.y * v.y; dist += v.z * v.z; dist += v.w * v.w;
+      }
+    } else {
+      for (int d = 0; d < D; ++d) dist += r[d] * r[d];
+    }
+    dist = sqrtf(dist);
+    const float T = 1.0f / (1.0f + dist);
+    top[row0 + threadIdx.x] = T;
+    if (BWD) {
+      float c; double den;
+      euclid_coef(T, top_diff[row0 + threadIdx.x], c, den);
+      cs[threadIdx.x] = c;
+      dens[threadIdx.x] = den;
+    }
+  }
+  if (!BWD) return;
+  __syncthreads();
+
+  // dq = 0 + tt ; da = 0 + (-tt)   (:176-177 zero, :219-220 accumulate once)
+  if (VEC4) {
+    const int D4 = D >> 2;
+    const float4* d4 = reinterpret_cast<const float4*>(diff);
+    float4* dq4 = reinterpret_cast<float4*>(dq + base);
+    float4* da4 = reinterpret_cast<float4*>(da + base);
+    for (int i = threadIdx.x; i < (total >> 2); i += THREADS) {
+      const int r = i / D4;
+      const float c = cs[r];
+      const double den = dens[r];
+      const float4 d = d4[i];
+      float4 t;
+      t.x = euclid_tt(c, den, d.x); t.y = euclid_tt(c, den, d.y);
+      t.z = euclid_tt(c, den, d.z); t.w = euclid_tt(c, den, d.w);
+      float4 o0, o1;
+      o0.x = 0.f + t.x; o0.y = 0.f + t.y; o0.z = 0.f + t.z; o0.w = 0.f + t.w;
+      o1.x = 0.f + (-t.x); o1.y = 0.f + (-t.y); o1.z = 0.f + (-t.z); o1.w = 0.f + (-t.w);
+      dq4[i] = o0;
+      da4[i] = o1;
+    }
+  } else {
+    for (int i = threadIdx.x; i < total; i += THREADS) {
+      const int r = i / D;
+      const float t = euclid_tt(cs[r], dens[r], diff[i]);
+      dq[base + i] = 0.f + t;
+      da[base + i] = 0.f + (-t);
+    }
+  }
+}
+
+// Backward alone for W1=W2=1, Euclidean: pure streaming, one 16-byte access
+// per operand per lane.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void euclid_rows_bwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ a,
+    const float* __restrict__ top, const float* __restrict__ top_diff,
+    float* __restrict__ dq, float* __restrict__ da, long long total, int D) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  if (VEC4) {
+    const int D4 = D >> 2;
+    const float4* q4 = reinterpret_cast<const float4*>(q);
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    float4* dq4 = reinterpret_cast<float4*>(dq);
+    float4* da4 = reinterpret_cast<float4*>(da);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (total >> 2); i += stride) {
+      const long long r = i / D4;
+      float c; double den;
+      euclid_coef(top[r], top_diff[r], c, den);
+      const float4 x = q4[i], y = a4[i];
+      float4 t;
+      t.x = euclid_tt(c, den, x.x - y.x); t.y = euclid_tt(c, den, x.y - y.y);
+      t.z = euclid_tt(c, den, x.z - y.z); t.w = euclid_tt(c, den, x.w - y.w);
+      float4 o0, o1;
+      o0.x = 0.f + t.x; o0.y = 0.f + t.y; o0.z = 0.f + t.z; o0.w = 0.f + t.w;
+      o1.x = 0.f + (-t.x); o1.y = 0.f + (-t.y); o1.z = 0.f + (-t.z); o1.w = 0.f + (-t.w);
+      dq4[i] = o0;
+      da4[i] = o1;
+    }
+  } else {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const long long r = i / D;
+      float c; double den;
+      euclid_coef(top[r], top_diff[r], c, den);
+      const float t = euclid_tt(c, den, q[i] - a[i]);
+      dq[i] = 0.f + t;
+      da[i] = 0.f + (-t);
+    }
+  }
+}
+
+// Cosine, W1=W2=1: one wave per pair; three dot products reduced with a fixed
+// butterfly (the reference's order here is whatever its BLAS does).
+// BWD fuses the backward with a known top_diff.
+template <bool VEC4, bool FWD, bool BWD>
+__global__ __launch_bounds__(256) void cosine_rows_kernel(
+    const float* __restrict__ q, const float* __restrict__ a,
+    const float* __restrict__ top_diff, float* __restrict__ top,
+    float* __restrict__ norm0, float* __restrict__ norm1,
+    float* __restrict__ dq, float* __restrict__ da, int N, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float* qr = q + (size_t)row * D;
+  const float* ar = a + (size_t)row * D;
+  float T, n0, n1;
+  if (FWD) {
+    float sqq = 0.f, saa = 0.f, sqa = 0.f;
+    if (VEC4) {
+      const float4* q4 = reinterpret_cast<const float4*>(qr);
+      const float4* a4 = reinterpret_cast<const float4*>(ar);
+      for (int i = lane; i < (D >> 2); i += 64) {
+        const float4 x = q4[i], y = a4[i];
+        sqq += x.x * x.x; sqq += x.y * x.y; sqq += x.z * x.z; sqq += x.w * x.w;
+        saa += y.x * y.x; saa += y.y * y.y; saa += y.z * y.z; saa += y.w * y.w;
+        sqa += x.x * y.x; sqa += x.y * y.y; sqa += x.z * y.z; sqa += x.w * y.w;
+      }
+    } else {
+      for (int i = lane; i < D; i += 64) {
+        const float x = qr[i], y = ar[i];
+        sqq += x * x; saa += y * y; sqa += x * y;
+      }
+    }
+    sqq = wave_sum(sqq); saa = wave_sum(saa); sqa = wave_sum(sqa);
+    n0 = sqrtf(sqq);
+    n1 = sqrtf(saa);
+    T = sqa / n0 / n1;  // two successive divisions (:135)
+    if (lane == 0) { top[row] = T; norm0[row] = n0; norm1[row] = n1; }
+  } else {
+    T = top[row]; n0 = norm0[row]; n1 = norm1[row];
+  }
+  if (!BWD) return;
+  const float g = top_diff[row];
+  float* dqr = dq + (size_t)row * D;
+  float* dar = da + (size_t)row * D;
+  // :239-245   dq += g*(a/n0/n1 - q*T/(n0*n0)) ; da += g*(q/n0/n1 - a*T/(n1*n1))
+  const float n00 = n0 * n0, n11 = n1 * n1;
+  if (VEC4) {
+    const float4* q4 = reinterpret_cast<const float4*>(qr);
+    const float4* a4 = reinterpret_cast<const float4*>(ar);
+    float4* dq4 = reinterpret_cast<float4*>(dqr);
+    float4* da4 = reinterpret_cast<float4*>(dar);
+    for (int i = lane; i < (D >> 2); i += 64) {
+      const float4 x = q4[i], y = a4[i];
+      float4 o0, o1;
+      o0.x = 0.f + g * (y.x / n0 / n1 - x.x * T / n00);
+      o0.y = 0.f + g * (y.y / n0 / n1 - x.y * T / n00);
+      o0.z = 0.f + g * (y.z / n0 / n1 - x.z * T / n00);
+      o0.w = 0.f + g * (y.w / n0 / n1 - x.w * T / n00);
+      o1.x = 0.f + g * (x.x / n0 / n1 - y.x * T / n11);
+      o1.y = 0.f + g * (x.y / n0 / n1 - y.y * T / n11);
+      o1.z = 0.f + g * (x.z / n0 / n1 - y.z * T / n11);
+      o1.w = 0.f + g * (x.w / n0 / n1 - y.w * T / n11);
+      dq4[i] = o0;
+      da4[i] = o1;
+    }
+  } else {
+    for (int i = lane; i < D; i += 64) {
+      const float x = qr[i], y = ar[i];
+      dqr[i] = 0.f + g * (y / n0 / n1 - x * T / n00);
+      dar[i] = 0.f + g * (x / n0 / n1 - y * T / n11);
+    }
+  }
+}
+
+// ============================== cross geometry ==============================
+
+// L2 norms of `rows` rows of length D: one wave per row (cosine, general W).
+__global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ x,
+                                                       float* __restrict__ nrm,
+                                                       long long rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* r = x + row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += r[i] * r[i];
+  s = wave_sum(s);
+  if (lane == 0) nrm[row] = sqrtf(s);
+}
+
+// Forward for general W1 x W2, MODE 0 (cosine; norms precomputed) or 1.
+// One wave per (pair, j-tile, k-tile); tile = (8*RJ) x (8*RK) outputs,
+// lane (lj = lane>>3, lk = lane&7) owns outputs j = j0+lj+8*rj, k = k0+lk+8*rk.
+// q/a are staged DC floats of d at a time in LDS with stride DC+1 (bank =
+// (row + d) mod 32: conflict-free across rows, broadcast within a row).
+template <int RJ, int RK, int MODE>
+__global__ __launch_bounds__(256) void cross_fwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ a,
+    const float* __restrict__ norm0, const float* __restrict__ norm1,
+    float* __restrict__ top, int N, int W1, int W2, int D, int tilesJ, int tilesK) {
+  constexpr int TJ = 8 * RJ, TK = 8 * RK, DC = 32, LS = DC + 1;
+  __shared__ float qs[4][TJ * LS];
+  __shared__ float as[4][TK * LS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long work = (long long)blockIdx.x * 4 + wave;
+  const long long total = (long long)N * tilesJ * tilesK;
+  const bool valid = work < total;
+  const long long w = valid ? work : 0;
+  const int n = (int)(w / (tilesJ * tilesK));
+  const int rem = (int)(w % (tilesJ * tilesK));
+  const int j0 = (rem / tilesK) * TJ, k0 = (rem % tilesK) * TK;
+  const int lj = lane >> 3, lk = lane & 7;
+  const float* qn = q + (size_t)n * W1 * D;
+  const float* an = a + (size_t)n * W2 * D;
+
+  float acc[RJ][RK];
+#pragma unroll
+  for (int x = 0; x < RJ; ++x)
+#pragma unroll
+    for (int y = 0; y < RK; ++y) acc[x][y] = 0.f;
+
+  const int lrow = lane >> 5, lcol = lane & 31;
+  for (int d0 = 0; d0 < D; d0 += DC) {
+    const int dn = min(DC, D - d0);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TJ; r += 2) {
+      const int j = j0 + r + lrow;
+      qs[wave][(r + lrow) * LS + lcol] =
+          (valid && j < W1 && lcol < dn) ? qn[(size_t)j * D + d0 + lcol] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < TK; r += 2) {
+      const int k = k0 + r + lrow;
+      as[wave][(r + lrow) * LS + lcol] =
+          (valid && k < W2 && lcol < dn) ? an[(size_t)k * D + d0 + lcol] : 0.f;
+    }
+    __syncthreads();
+    for (int dd = 0; dd < dn; ++dd) {
+      float qv[RJ], av[RK];
+#pragma unroll
+      for (int x = 0; x < RJ; ++x) qv[x] = qs[wave][(lj + 8 * x) * LS + dd];
+#pragma unroll
+      for (int y = 0; y < RK; ++y) av[y] = as[wave][(lk + 8 * y) * LS + dd];
+#pragma unroll
+      for (int x = 0; x < RJ; ++x)
+#pragma unroll
+        for (int y = 0; y < RK; ++y) {
+          if (MODE == 1) {
+            const float df = qv[x] - av[y];
+            acc[x][y] += df * df;
+          } else {
+            acc[x][y] += qv[x] * av[y];
+          }
+        }
+    }
+  }
+  if (!valid) return;
+#pragma unroll
+  for (int x = 0; x < RJ; ++x) {
+    const int j = j0 + lj + 8 * x;
+    if (j >= W1) continue;
+#pragma unroll
+    for (int y = 0; y < RK; ++y) {
+      const int k = k0 + lk + 8 * y;
+      if (k >= W2) continue;
+      float T;
+      if (MODE == 1) {
+        T = 1.0f / (1.0f + sqrtf(acc[x][y]));
+      } else {
+        T = acc[x][y] / norm0[(size_t)n * W1 + j] / norm1[(size_t)n * W2 + k];
+      }
+      top[((size_t)n * W1 + j) * W2 + k] = T;
+    }
+  }
+}
+
+// Backward for general W1 x W2, MODE 0/1: one workgroup per pair n.  Thread
+// owns one (j,d) of dq and walks k ascending, then one (k,d) of da and walks
+// j ascending -- the reference's accumulation order (:209-223), so Euclidean
+// is bit-exact.  q/a/top rows of one n stay L1/L2-resident across the walk.
+template <int MODE>
+__global__ __launch_bounds__(256) void cross_bwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ a,
+    const float* __restrict__ top, const float* __restrict__ top_diff,
+    const float* __restrict__ norm0, const float* __restrict__ norm1,
+    float* __restrict__ dq, float* __restrict__ da, int W1, int W2, int D) {
+  const int n = blockIdx.x;
+  const float* qn = q + (size_t)n * W1 * D;
+  const float* an = a + (size_t)n * W2 * D;
+  const float* Tn = top + (size_t)n * W1 * W2;
+  const float* gn = top_diff + (size_t)n * W1 * W2;
+  float* dqn = dq + (size_t)n * W1 * D;
+  float* dan = da + (size_t)n * W2 * D;
+  const float* n0n = MODE == 0 ? norm0 + (size_t)n * W1 : nullptr;
+  const float* n1n = MODE == 0 ? norm1 + (size_t)n * W2 : nullptr;
+
+  for (int e = threadIdx.x; e < W1 * D; e += 256) {
+    const int j = e / D, d = e - j * D;
+    const float qv = qn[e];
+    float acc = 0.f;
+    if (MODE == 1) {
+      for (int k = 0; k < W2; ++k) {
+        float c; double den;
+        euclid_coef(Tn[j * W2 + k], gn[j * W2 + k], c, den);
+        acc += euclid_tt(c, den, qv - an[(size_t)k * D + d]);
+      }
+    } else {
+      const float nrm0 = n0n[j];
+      for (int k = 0; k < W2; ++k) {
+        const float nrm1 = n1n[k];
+        acc += gn[j * W2 + k] * (an[(size_t)k * D + d] / nrm0 / nrm1 -
+                                 qv * Tn[j * W2 + k] / (nrm0 * nrm0));
+      }
+    }
+    dqn[e] = acc;
+  }
+  for (int e = threadIdx.x; e < W2 * D; e += 256) {
+    const int k = e / D, d = e - k * D;
+    const float av = an[e];
+    float acc = 0.f;
+    if (MODE == 1) {
+      for (int j = 0; j < W1; ++j) {
+        float c; double den;
+        euclid_coef(Tn[j * W2 + k], gn[j * W2 + k], c, den);
+        acc += -euclid_tt(c, den, qn[(size_t)j * D + d] - av);
+      }
+    } else {
+      const float nrm1 = n1n[k];
+      for (int j = 0; j < W1; ++j) {
+        const float nrm0 = n0n[j];
+        acc += gn[j * W2 + k] * (qn[(size_t)j * D + d] / nrm0 / nrm1 -
+                                 av * Tn[j * W2 + k] / (nrm1 * nrm1));
+      }
+    }
+    dan[e] = acc;
+  }
+}
+
+// ================================ dispatch ==================================
+
+template <int MODE>
+static void launch_cross_fwd(const float* q, const float* a, const float* n0,
+                             const float* n1, float* top, int N, int W1, int W2,
+                             int D, hipStream_t s) {
+  auto r_of = [](int w) { int r = (w + 7) / 8; return r > 5 ? 5 : r; };
+  const int rj = r_of(W1), rk = r_of(W2);
+  const int tilesJ = (W1 + 8 * rj - 1) / (8 * rj), tilesK = (W2 + 8 * rk - 1) / (8 * rk);
+  const long long work = (long long)N * tilesJ * tilesK;
+  const unsigned grid = (unsigned)((work + 3) / 4);
+#define MMS_CROSS_CASE(J, K)                                                        \
+  if (rj == J && rk == K) {                                                         \
+    hipLaunchKernelGGL((cross_fwd_kernel<J, K, MODE>), dim3(grid), dim3(256), 0, s, \
+                       q, a, n0, n1, top, N, W1, W2, D, tilesJ, tilesK);            \
+    return;                                                                         \
+  }
+#define MMS_CROSS_ROW(J) MMS_CROSS_CASE(J, 1) MMS_CROSS_CASE(J, 2) MMS_CROSS_CASE(J, 3) \
+                         MMS_CROSS_CASE(J, 4) MMS_CROSS_CASE(J, 5)
+  MMS_CROSS_ROW(1) MMS_CROSS_ROW(2) MMS_CROSS_ROW(3) MMS_CROSS_ROW(4) MMS_CROSS_ROW(5)
+#undef MMS_CROSS_ROW
+#undef MMS_CROSS_CASE
+}
+
+constexpr int kRows = 8;       // pairs per workgroup in the rows kernels
+constexpr int kRowsThreads = 256;
+
+static bool vec4_ok(int D, const void* p0, const void* p1, const void* p2, const void* p3) {
+  return (D % 4 == 0) && aligned16(p0) && aligned16(p1) && (!p2 || aligned16(p2)) &&
+         (!p3 || aligned16(p3));
+}
+
+// LDS the rows kernel needs; falls back to the cross kernels above ~64 KB.
+static size_t rows_lds_bytes(int D) { return (size_t)kRows * D * sizeof(float); }
+static bool rows_fit(int D) { return rows_lds_bytes(D) <= 64 * 1024; }
+
+int simcross_elementwise_forward(int mode, int N, int W1, int W2, int D,
+                                 const float* q, const float* a, float* top,
+                                 float* norm0, float* norm1, hipStream_t s) {
+  if (N == 0) return MMS_OK;
+  const bool rows = (W1 == 1 && W2 == 1);
+  if (mode == 1) {
+    if (rows && rows_fit(D)) {
+      const unsigned grid = (N + kRows - 1) / kRows;
+      if (vec4_ok(D, q, a, nullptr, nullptr))
+        hipLaunchKernelGGL((euclid_rows_kernel<kRows, kRowsThreads, true, false>), dim3(grid),
+                           dim3(kRowsThreads), rows_lds_bytes(D), s, q, a, nullptr, top,
+                           nullptr, nullptr, N, D);
+      else
+        hipLaunchKernelGGL((euclid_rows_kernel<kRows, kRowsThreads, false, false>), dim3(grid),
+                           dim3(kRowsThreads), rows_lds_bytes(D), s, q, a, nullptr, top,
+                           nullptr, nullptr, N, D);
+    } else {
+      launch_cross_fwd<1>(q, a, nullptr, nullptr, top, N, W1, W2, D, s);
+    }
+  } else {
+    if (rows) {
+      const unsigned grid = (N + 3) / 4;
+      if (vec4_ok(D, q, a, nullptr, nullptr))
+        hipLaunchKernelGGL((cosine_rows_kernel<true, true, false>), dim3(grid), dim3(256), 0, s,
+                           q, a, nullptr, top, norm0, norm1, nullptr, nullptr, N, D);
+      else
+        hipLaunchKernelGGL((cosine_rows_kernel<false, true, false>), dim3(grid), dim3(256), 0, s,
+                           q, a, nullptr, top, norm0, norm1, nullptr, nullptr, N, D);
+    } else {
+      const long long r0 = (long long)N * W1, r1 = (long long)N * W2;
+      hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)((r0 + 3) / 4)), dim3(256), 0, s, q, norm0, r0, D);
+      hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)((r1 + 3) / 4)), dim3(256), 0, s, a, norm1, r1, D);
+      launch_cross_fwd<0>(q, a, norm0, norm1, top, N, W1, W2, D, s);
+    }
+  }
+  return launch_status();
+}
+
+int simcross_elementwise_backward(int mode, int N, int W1, int W2, int D,
+                                  const float* q, const float* a, const float* top,
+                                  const float* top_diff, const float* norm0,
+                                  const float* norm1, float* dq, float* da,
+                                  hipStream_t s) {
+  if (N == 0) return MMS_OK;
+  const bool rows = (W1 == 1 && W2 == 1);
+  if (rows && mode == 1) {
+    const long long total = (long long)N * D;
+    const bool v = vec4_ok(D, q, a, dq, da);
+    const long long items = v ? total / 4 : total;
+    long long blocks = (items + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (v)
+      hipLaunchKernelGGL((euclid_rows_bwd_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s,
+                         q, a, top, top_diff, dq, da, total, D);
+    else
+      hipLaunchKernelGGL((euclid_rows_bwd_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s,
+                         q, a, top, top_diff, dq, da, total, D);
+  } else if (rows && mode == 0) {
+    const unsigned grid = (N + 3) / 4;
+    if (vec4_ok(D, q, a, dq, da))
+      hipLaunchKernelGGL((cosine_rows_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, q, a,
+                         top_diff, const_cast<float*>(top), const_cast<float*>(norm0),
+                         const_cast<float*>(norm1), dq, da, N, D);
+    else
+      hipLaunchKernelGGL((cosine_rows_kernel<false, false, true>), dim3(grid), dim3(256), 0, s, q, a,
+                         top_diff, const_cast<float*>(top), const_cast<float*>(norm0),
+                         const_cast<float*>(norm1), dq, da, N, D);
+  } else if (mode == 1) {
+    hipLaunchKernelGGL((cross_bwd_kernel<1>), dim3(N), dim3(256), 0, s, q, a, top, top_diff,
+                       nullptr, nullptr, dq, da, W1, W2, D);
+  } else {
+    hipLaunchKernelGGL((cross_bwd_kernel<0>), dim3(N), dim3(256), 0, s, q, a, top, top_diff,
+                       norm0, norm1, dq, da, W1, W2, D);
+  }
+  return launch_status();
+}
+
+// Forward+backward in one launch where the geometry allows (rows); otherwise
+// the two passes back to back.
+int simcross_elementwise_forward_backward(int mode, int N, int W1, int W2, int D,
+                                          const float* q, const float* a,
+                                          const float* top_diff, float* top,
+                                          float* norm0, float* norm1, float* dq,
+                                          float* da, hipStream_t s) {
+  if (N == 0) return MMS_OK;
+  const bool rows = (W1 == 1 && W2 == 1);
+  if (rows && mode == 1 && rows_fit(D)) {
+    const unsigned grid = (N + kRows - 1) / kRows;
+    if (vec4_ok(D, q, a, dq, da))
+      hipLaunchKernelGGL((euclid_rows_kernel<kRows, kRowsThreads, true, true>), dim3(grid),
+                         dim3(kRowsThreads), rows_lds_bytes(D), s, q, a, top_diff, top, dq, da, N, D);
+    else
+      hipLaunchKernelGGL((euclid_rows_kernel<kRows, kRowsThreads, false, true>), dim3(grid),
+                         dim3(kRowsThreads), rows_lds_bytes(D), s, q, a, top_diff, top, dq, da, N, D);
+    return launch_status();
+  }
+  if (rows && mode == 0) {
+    const unsigned grid = (N + 3) / 4;
+    if (vec4_ok(D, q, a, dq, da))
+      hipLaunchKernelGGL((cosine_rows_kernel<true, true, true>), dim3(grid), dim3(256), 0, s, q, a,
+                         top_diff, top, norm0, norm1, dq, da, N, D);
+    else
+      hipLaunchKernelGGL((cosine_rows_kernel<false, true, true>), dim3(grid), dim3(256), 0, s, q, a,
+                         top_diff, top, norm0, norm1, dq, da, N, D);
+    return launch_status();
+  }
+  int rc = simcross_elementwise_forward(mode, N, W1, W2, D, q, a, top, norm0, norm1, s);
+  if (rc != MMS_OK) return rc;
+  return simcross_elementwise_backward(mode, N, W1, W2, D, q, a, top, top_diff, norm0, norm1,
+                                       dq, da, s);
+}
+
+}  // namespace mms

@@ -1,0 +1,364 @@
+"""GPU parity: the HIP path, called through the C ABI (include/mms.h), against the
+CPU oracle (oracle/) on the same seeded inputs.
+
+Bars (DESIGN.md "Numerics"):
+  * bit-exact where the reference's own source fixes the evaluation order:
+    Euclidean SimCross forward/backward (sim_cross_layer.cpp:96-111, 208-225),
+    PairRankLoss cached terms and gradients (pair_rank_loss_layer.cpp:28-37, 61-82),
+    dbias (sim_cross_layer.cpp:301-304);
+  * TOL = 1e-5 (north_star) where the reference goes through CBLAS (cosine,
+    bilinear, SimMatrix) or a long scalar running sum (the loss value).
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import TOL, assert_bitexact, assert_close, qa, rng
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def nan_like(shape):
+    return torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
+
+
+# --------------------------------------------------------------------------- #
+# SimCross Euclidean (dist_mode 1): bit-exact
+# --------------------------------------------------------------------------- #
+EUCLID_SHAPES = [
+    (8, 1, 1, 300),      # golden-vector shape
+    (4096, 1, 1, 300),   # BASELINE cfg 2, full size
+    (37, 1, 1, 301),     # D % 4 != 0 -> scalar path, ragged last workgroup
+    (5, 1, 1, 4),
+    (1, 1, 1, 1),
+    (4, 5, 7, 300),      # W1 != W2
+    (2, 40, 40, 50),     # the reference's network_v4 geometry (do_trec_qa_clean.py:468)
+    (3, 41, 9, 33),      # tile remainders
+    (2, 1, 6, 20),
+]
+
+
+@pytest.mark.parametrize("shape", EUCLID_SHAPES)
+def test_euclid_forward_backward_bitexact(shape, oracle, hiplib):
+    from mms_answer_selection_amd import capi
+    N, W1, W2, D = shape
+    r = rng(sum(shape))
+    q, a = qa(r, N, W1, W2, D)
+    if N >= 4:
+        a[1, 0] = q[1, 0]                       # degenerate pair: T = 1, divisor 1e-9
+        a[2, W2 - 1, : D // 2] = q[2, W1 - 1, : D // 2]
+    dT = r.standard_normal((N, 1, W1, W2)).astype(np.float32)
+    top_ref, _, _ = oracle.simcross_forward(1, q, a)
+    dq_ref, da_ref, _, _ = oracle.simcross_backward(1, q, a, top_ref, dT)
+
+    dq_, da_, dT_ = dev(q), dev(a), dev(dT)
+    top = nan_like(top_ref.shape)
+    capi.simcross_forward(1, dq_, da_, top)
+    assert_bitexact(host(top), top_ref, "top")
+
+    gq, ga = nan_like(q.shape), nan_like(a.shape)
+    capi.simcross_backward(1, dq_, da_, top, dT_, gq, ga)
+    assert_bitexact(host(gq), dq_ref, "dq")
+    assert_bitexact(host(ga), da_ref, "da")
+
+    # one-launch forward+backward gives the same bits
+    top2, gq2, ga2 = nan_like(top_ref.shape), nan_like(q.shape), nan_like(a.shape)
+    capi.simcross_forward_backward(1, dq_, da_, dT_, top2, gq2, ga2)
+    assert_bitexact(host(top2), top_ref, "fused top")
+    assert_bitexact(host(gq2), dq_ref, "fused dq")
+    assert_bitexact(host(ga2), da_ref, "fused da")
+
+
+def test_euclid_unaligned_views_take_scalar_path(oracle, hiplib):
+    """Pointers that are not 16-byte aligned must still give the same bits."""
+    from mms_answer_selection_amd import capi
+    N, D = 19, 300
+    r = rng(5)
+    q, a = qa(r, N, 1, 1, D)
+    dT = r.standard_normal((N, 1, 1, 1)).astype(np.float32)
+    top_ref, _, _ = oracle.simcross_forward(1, q, a)
+    dq_ref, da_ref, _, _ = oracle.simcross_backward(1, q, a, top_ref, dT)
+
+    def shifted(x):
+        buf = torch.empty(x.size + 1, dtype=torch.float32, device="cuda")
+        v = buf[1:].view(x.shape)
+        v.copy_(torch.from_numpy(x))
+        assert v.data_ptr() % 16 != 0
+        return v
+
+    qd, ad = shifted(q), shifted(a)
+    top, gq, ga = nan_like(top_ref.shape), nan_like(q.shape), nan_like(a.shape)
+    capi.simcross_forward_backward(1, qd, ad, dev(dT), top, gq, ga)
+    assert_bitexact(host(top), top_ref)
+    assert_bitexact(host(gq), dq_ref)
+    assert_bitexact(host(ga), da_ref)
+
+
+def test_backward_without_propagate_down_zeroes_both(hiplib):
+    """sim_cross_layer.cpp:176-177,201."""
+    from mms_answer_selection_amd import capi
+    N, W1, W2, D = 3, 2, 3, 8
+    q, a = qa(rng(), N, W1, W2, D)
+    top = torch.rand(N, 1, W1, W2, device="cuda")
+    gq, ga = nan_like(q.shape), nan_like(a.shape)
+    capi.simcross_backward(1, dev(q), dev(a), top, torch.ones_like(top), gq, ga,
+                           propagate_down=(False, False))
+    assert (host(gq) == 0).all() and (host(ga) == 0).all()
+
+
+# --------------------------------------------------------------------------- #
+# SimCross cosine (dist_mode 0): 1e-5 (BLAS order in the reference)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("shape", [(8, 1, 1, 300), (4096, 1, 1, 300), (9, 1, 1, 7),
+                                   (4, 5, 7, 300), (2, 40, 40, 50), (3, 41, 9, 33)])
+def test_cosine_forward_backward(shape, oracle, hiplib):
+    from mms_answer_selection_amd import capi
+    N, W1, W2, D = shape
+    r = rng(sum(shape) + 1)
+    q, a = qa(r, N, W1, W2, D)
+    dT = r.standard_normal((N, 1, W1, W2)).astype(np.float32)
+    top_ref, n0_ref, n1_ref = oracle.simcross_forward(0, q, a)
+    dq_ref, da_ref, _, _ = oracle.simcross_backward(0, q, a, top_ref, dT, norm0=n0_ref, norm1=n1_ref)
+
+    qd, ad, dTd = dev(q), dev(a), dev(dT)
+    top, n0, n1 = nan_like(top_ref.shape), nan_like(n0_ref.shape), nan_like(n1_ref.shape)
+    capi.simcross_forward(0, qd, ad, top, norm0=n0, norm1=n1)
+    assert_close(host(top), top_ref, TOL, "top")
+    assert_close(host(n0), n0_ref, TOL, "norm0")   # the NORM, as the CPU code caches it
+    assert_close(host(n1), n1_ref, TOL, "norm1")
+    gq, ga = nan_like(q.shape), nan_like(a.shape)
+    capi.simcross_backward(0, qd, ad, top, dTd, gq, ga, norm0=n0, norm1=n1)
+    assert_close(host(gq), dq_ref, TOL, "dq")
+    assert_close(host(ga), da_ref, TOL, "da")
+
+    top2, n02, n12 = nan_like(top_ref.shape), nan_like(n0_ref.shape), nan_like(n1_ref.shape)
+    gq2, ga2 = nan_like(q.shape), nan_like(a.shape)
+    capi.simcross_forward_backward(0, qd, ad, dTd, top2, gq2, ga2, norm0=n02, norm1=n12)
+    assert_bitexact(host(top2), host(top), "fused top vs two-call")
+    assert_bitexact(host(gq2), host(gq), "fused dq vs two-call")
+    assert_bitexact(host(ga2), host(ga), "fused da vs two-call")
+
+
+# --------------------------------------------------------------------------- #
+# SimCross bilinear (dist_mode 2) on MFMA: 1e-5
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("cfg", [
+    (8, 1, 1, 300, 1, False),
+    (4, 5, 7, 300, 2, True),
+    (2, 40, 40, 50, 4, True),     # network_v4: mesure_count 4, bias_term true
+    (3, 9, 4, 33, 3, True),
+    (300, 1, 1, 64, 2, True),
+    (1, 130, 70, 20, 1, False),   # more than one output tile per pair
+])
+def test_bilinear_forward_backward(cfg, oracle, hiplib):
+    from mms_answer_selection_amd import capi
+    N, W1, W2, D, M, bias_term = cfg
+    r = rng(sum(cfg[:5]) + 2)
+    q, a = qa(r, N, W1, W2, D)
+    W = r.uniform(-0.08, 0.08, (M, D, D)).astype(np.float32)
+    bias = r.standard_normal((M, W1, W2)).astype(np.float32) if bias_term else None
+    dT = r.standard_normal((N, M, W1, W2)).astype(np.float32)
+    dbias0 = r.standard_normal((M, W1, W2)).astype(np.float32) if bias_term else None
+    top_ref, _, _ = oracle.simcross_forward(2, q, a, W, bias)
+    dq_ref, da_ref, dW_ref, db_ref = oracle.simcross_backward(
+        2, q, a, top_ref, dT, W=W, bias_term=bias_term, dbias_in=dbias0)
+
+    qd, ad, Wd, bd, dTd = dev(q), dev(a), dev(W), dev(bias), dev(dT)
+    top = nan_like(top_ref.shape)
+    capi.simcross_forward(2, qd, ad, top, W=Wd, bias=bd)
+    assert_close(host(top), top_ref, TOL, "top")
+    gq, ga, gW = nan_like(q.shape), nan_like(a.shape), nan_like(W.shape)
+    gb = dev(dbias0)
+    capi.simcross_backward(2, qd, ad, top, dTd, gq, ga, W=Wd, bias_term=bias_term, dW=gW, dbias=gb)
+    assert_close(host(gq), dq_ref, TOL, "dq")
+    assert_close(host(ga), da_ref, TOL, "da")
+    assert_close(host(gW), dW_ref, TOL, "dW (overwritten: W.diff zeroed at :256)")
+    if bias_term:
+        assert_bitexact(host(gb), db_ref, "dbias (accumulated, n ascending)")
+
+
+# --------------------------------------------------------------------------- #
+# SimMatrix: 1e-5
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("shape", [(16, 300, 300), (5, 7, 3), (700, 64, 48), (1, 1, 1)])
+def test_simmatrix(shape, oracle, hiplib):
+    from mms_answer_selection_amd import capi
+    N, K1, K2 = shape
+    r = rng(sum(shape) + 3)
+    q = (r.standard_normal((N, K1)) * 0.4).astype(np.float32)
+    a = (r.standard_normal((N, K2)) * 0.4).astype(np.float32)
+    W = r.uniform(-0.08, 0.08, (K1, K2)).astype(np.float32)
+    dT = r.standard_normal((N, 1)).astype(np.float32)
+    dW0 = r.standard_normal((K1, K2)).astype(np.float32)
+    top_ref, scratch_ref = oracle.simmatrix_forward(q, a, W)
+    dq_ref, da_ref, dW_ref = oracle.simmatrix_backward(q, a, W, dT, dW_in=dW0)
+
+    qd, ad, Wd, dTd = dev(q), dev(a), dev(W), dev(dT)
+    top, scratch = nan_like((N, 1)), nan_like((N, K2))
+    capi.simmatrix_forward(qd, ad, Wd, top, scratch)
+    assert_close(host(top), top_ref, TOL, "top")
+    assert_close(host(scratch), scratch_ref, TOL, "Q*W left in bottom[1].diff (:58)")
+    gq, ga, gW = nan_like((N, K1)), nan_like((N, K2)), dev(dW0)
+    capi.simmatrix_backward(qd, ad, Wd, dTd, gq, ga, gW)
+    assert_close(host(gq), dq_ref, TOL, "dq")
+    assert_close(host(ga), da_ref, TOL, "da")
+    assert_close(host(gW), dW_ref, TOL, "dW (accumulated)")
+
+    # propagate_down flags: untouched outputs stay untouched (:81-93)
+    gq2, ga2, gW2 = nan_like((N, K1)), nan_like((N, K2)), dev(dW0)
+    capi.simmatrix_backward(qd, ad, Wd, dTd, gq2, ga2, gW2, param_propagate_down=False,
+                            propagate_down=(False, True))
+    assert np.isnan(host(gq2)).all()
+    assert_bitexact(host(gW2), dW0, "dW untouched")
+    assert_bitexact(host(ga2), host(ga), "da")
+
+
+# --------------------------------------------------------------------------- #
+# PairRankLoss
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("cfg", [(64, 1, 1.0), (8, 5, 0.1), (4096, 1, 1.0), (100003, 1, 0.5)])
+def test_pairrank(cfg, oracle, hiplib):
+    from mms_answer_selection_amd import capi
+    N, Cc, margin = cfg
+    r = rng(N + Cc)
+    a = r.uniform(0, 1, (N, Cc)).astype(np.float32)
+    b = r.uniform(0, 1, (N, Cc)).astype(np.float32)
+    y = (r.uniform(size=(N, Cc)) < 0.2).astype(np.float32)   # TREC-QA positive rate
+    a[0] = b[0]                                     # similar == 0 exactly
+    if N > 3:
+        a[1, 0], b[1, 0], y[1, 0] = 0.25, 0.25 + margin, 1.0   # tie at the hinge
+        a[2, 0], b[2, 0], y[2, 0] = 0.75, 0.25, 0.0            # (1-y)*similar > 0
+        a[3, 0], b[3, 0], y[3, 0] = 0.25, 0.75, 0.0            # (1-y)*similar < 0
+    loss_ref, ord_ref, sim_ref = oracle.pairrank_forward(a, b, y, margin)
+    da_ref, db_ref = oracle.pairrank_backward(y, ord_ref, sim_ref, top_diff=2.0)
+
+    ad, bd, yd = dev(a), dev(b), dev(y)
+    o, s, loss = nan_like(a.shape), nan_like(a.shape), nan_like((1,))
+    capi.pairrank_forward(ad, bd, yd, o, s, loss, margin=margin)
+    assert_bitexact(host(o), ord_ref, "ordered_diff_")
+    assert_bitexact(host(s), sim_ref, "similar_diff_")
+    assert_close(host(loss)[0], loss_ref, TOL, "loss")
+    ga, gb = nan_like(a.shape), nan_like(a.shape)
+    capi.pairrank_backward(yd, o, s, ga, gb, top_diff=2.0)
+    assert_bitexact(host(ga), da_ref, "da")
+    assert_bitexact(host(gb), db_ref, "db")
+    # only bottom[1]
+    ga2, gb2 = nan_like(a.shape), nan_like(a.shape)
+    capi.pairrank_backward(yd, o, s, ga2, gb2, top_diff=2.0, propagate_down=(False, True))
+    assert np.isnan(host(ga2)).all()
+    assert_bitexact(host(gb2), db_ref)
+
+
+# --------------------------------------------------------------------------- #
+# Fused (q, a+, a-) step == layer-by-layer oracle
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("cfg", [(8, 300), (4096, 300), (77, 301), (5, 4)])
+def test_triplet_step(cfg, oracle, hiplib):
+    from mms_answer_selection_amd import capi
+    N, D = cfg
+    margin, lw = 0.05, 1.0
+    r = rng(N + D)
+    q, ap = qa(r, N, 1, 1, D)
+    _, an = qa(r, N, 1, 1, D)
+    ap = (q + 0.1 * ap).astype(np.float32)          # positives closer than negatives, mostly
+    y = (r.uniform(size=(N, 1)) < 0.8).astype(np.float32)
+    sp, _, _ = oracle.simcross_forward(1, q, ap)
+    sn, _, _ = oracle.simcross_forward(1, q, an)
+    loss_ref, o, s = oracle.pairrank_forward(sp.reshape(N, 1), sn.reshape(N, 1), y, margin)
+    gsp, gsn = oracle.pairrank_backward(y, o, s, top_diff=lw)
+    dq_p, dap_ref, _, _ = oracle.simcross_backward(1, q, ap, sp, gsp.reshape(sp.shape))
+    dq_n, dan_ref, _, _ = oracle.simcross_backward(1, q, an, sn, gsn.reshape(sn.shape))
+    dq_ref = dq_p + dq_n                              # Split layer backward
+
+    out = dict(s_pos=nan_like((N, 1)), s_neg=nan_like((N, 1)), loss=nan_like((1,)),
+               dq=nan_like(q.shape), da_pos=nan_like(q.shape), da_neg=nan_like(q.shape))
+    capi.triplet_euclid_step(dev(q), dev(ap), dev(an), dev(y), margin=margin, loss_weight=lw, **out)
+    assert_bitexact(host(out["s_pos"]).ravel(), sp.ravel(), "s_pos")
+    assert_bitexact(host(out["s_neg"]).ravel(), sn.ravel(), "s_neg")
+    assert_close(host(out["loss"])[0], loss_ref, TOL, "loss")
+    assert_bitexact(host(out["dq"]), dq_ref, "dq")
+    assert_bitexact(host(out["da_pos"]), dap_ref, "da_pos")
+    assert_bitexact(host(out["da_neg"]), dan_ref, "da_neg")
+
+
+# --------------------------------------------------------------------------- #
+# Size-independent properties at full BASELINE sizes
+# --------------------------------------------------------------------------- #
+def test_properties_full_size(hiplib):
+    from mms_answer_selection_amd import capi
+    N, D = 4096, 300
+    g = torch.Generator(device="cuda").manual_seed(1701)
+    q = torch.randn(N, 1, D, device="cuda", generator=g) * 0.4
+    a = torch.randn(N, 1, D, device="cuda", generator=g) * 0.4
+    dT = torch.randn(N, 1, 1, 1, device="cuda", generator=g)
+    top, gq, ga = nan_like((N, 1, 1, 1)), nan_like(q.shape), nan_like(a.shape)
+    capi.simcross_forward_backward(1, q, a, dT, top, gq, ga)
+    t = host(top)
+    assert ((t > 0) & (t <= 1)).all()                        # range of 1/(1+dist)
+    assert_bitexact(host(ga), -host(gq), "da == -dq for W1=W2=1")
+    # symmetry: swapping q and a leaves T unchanged bitwise ((q-a)^2 == (a-q)^2)
+    top_s = nan_like((N, 1, 1, 1))
+    capi.simcross_forward(1, a, q, top_s)
+    assert_bitexact(host(top_s), t, "T(q,a) == T(a,q)")
+    # determinism: same bits on a second run
+    top2, gq2, ga2 = nan_like((N, 1, 1, 1)), nan_like(q.shape), nan_like(a.shape)
+    capi.simcross_forward_backward(1, q, a, dT, top2, gq2, ga2)
+    assert_bitexact(host(top2), t)
+    assert_bitexact(host(gq2), host(gq))
+    # linearity of backward in top_diff: dq(2*dT) == 2*dq(dT) (power of two: exact)
+    gq3, ga3 = nan_like(q.shape), nan_like(a.shape)
+    capi.simcross_backward(1, q, a, top, 2 * dT, gq3, ga3)
+    assert_bitexact(host(gq3), 2 * host(gq), "backward is linear in top_diff")
+
+
+def test_cfg3_simmatrix_full_size_against_fp64(hiplib):
+    """BASELINE cfg 3 (16384 x 300 x 300): fp64 closed form on the GPU box's host."""
+    from mms_answer_selection_amd import capi
+    N, K = 16384, 300
+    r = rng(33)
+    q = (r.standard_normal((N, K)) * 0.4).astype(np.float32)
+    a = (r.standard_normal((N, K)) * 0.4).astype(np.float32)
+    W = r.uniform(-0.08, 0.08, (K, K)).astype(np.float32)
+    dT = r.standard_normal((N, 1)).astype(np.float32)
+    qd, ad, Wd, dTd = dev(q), dev(a), dev(W), dev(dT)
+    top, scratch = nan_like((N, 1)), nan_like((N, K))
+    capi.simmatrix_forward(qd, ad, Wd, top, scratch)
+    q6, a6, W6, g6 = (x.astype(np.float64) for x in (q, a, W, dT))
+    assert_close(host(top), ((q6 @ W6) * a6).sum(1, keepdims=True), TOL, "top")
+    gq, ga = nan_like((N, K)), nan_like((N, K))
+    gW = torch.zeros(K, K, device="cuda")
+    capi.simmatrix_backward(qd, ad, Wd, dTd, gq, ga, gW)
+    assert_close(host(gq), g6 * (a6 @ W6.T), TOL, "dq")
+    assert_close(host(ga), g6 * (q6 @ W6), TOL, "da")
+    assert_close(host(gW), q6.T @ (g6 * a6), 2e-5, "dW (16384-term sums)")
+
+
+# --------------------------------------------------------------------------- #
+# Error behaviour of the C ABI
+# --------------------------------------------------------------------------- #
+def test_error_codes(hiplib):
+    from mms_answer_selection_amd import capi
+    L = hiplib
+    q = torch.zeros(2, 1, 4, device="cuda")
+    top = torch.zeros(2, 1, 1, 1, device="cuda")
+    p = q.data_ptr()
+    assert L.mms_simcross_forward_f32(3, 2, 1, 1, 4, 1, p, p, None, None, top.data_ptr(), None, None, None, 0, None) == 1
+    assert L.mms_simcross_forward_f32(1, 2, 1, 1, 4, 1, None, p, None, None, top.data_ptr(), None, None, None, 0, None) == 1
+    assert L.mms_simcross_forward_f32(1, 2, 1, 1, 4, 2, p, p, None, None, top.data_ptr(), None, None, None, 0, None) == 1
+    assert L.mms_simcross_forward_f32(0, 2, 1, 1, 4, 1, p, p, None, None, top.data_ptr(), None, None, None, 0, None) == 1  # norms required
+    assert L.mms_simcross_forward_f32(1, 0, 1, 1, 4, 1, None, None, None, None, None, None, None, None, 0, None) == 0   # empty batch
+    # bilinear without workspace
+    W = torch.zeros(1, 4, 4, device="cuda")
+    assert L.mms_simcross_forward_f32(2, 2, 1, 1, 4, 1, p, p, W.data_ptr(), None, top.data_ptr(), None, None, None, 0, None) == 3
+    assert L.mms_pairrank_forward_f32(0, 1.0, p, p, p, p, p, p, None, 0, None) == 1
+    assert L.mms_error_string(3).decode().startswith("workspace")
+    with pytest.raises(capi.MMSError):
+        capi.simcross_forward(1, q.cpu(), q.cpu(), top.cpu())     # host tensors are refused
