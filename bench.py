@@ -1,0 +1,345 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MMS hot path on MI355X.
+
+Metric (BASELINE.json): QA pairs/sec (fwd+bwd) at batch 4096, 300-d; % HBM roofline.
+Workload (cfg 2): SimCross dist_mode 1 (Euclidean), q,a (4096,1,300) fp32 ->
+T (4096,1,1,1), forward + backward with a given top_diff, per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one forward+backward pass over one 4096-pair batch through the C
+ABI (mms_simcross_forward_backward_f32: one launch).  Inputs are resident in
+HBM before the timed region.  To keep the numbers HBM-bound rather than
+Infinity-Cache-bound, the steps walk a ring of RING distinct batches
+(RING x 19.7 MB > 1 GiB >> 256 MiB of L3); `--warm` re-uses one batch instead.
+Steps are captured GROUP at a time into hipGraphs (launch-bound inner loop) and
+replayed; N > 1 shards pairs over ranks (weak scaling: 4096 pairs per GPU) and
+all-gathers the per-pair scores of each GROUP of steps with one RCCL call on a
+side stream, overlapped with the next group's compute.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
+and `cpu_baseline` objects added.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PAIRS, DIM = 4096, 300
+S = 4  # sizeof(float)
+# algorithmic bytes per fwd+bwd pass of SimCross modes 0/1
+B_FWD = S * (N_PAIRS * 2 * DIM + N_PAIRS)              # 9,846,784
+B_BWD = S * (2 * N_PAIRS * 2 * DIM + 2 * N_PAIRS)      # 19,693,568
+B_UNFUSED = B_FWD + B_BWD                              # 29,540,352  (7,212 B/pair)
+B_FUSED = S * (2 * N_PAIRS * 2 * DIM + 2 * N_PAIRS)    # q,a read once; dq,da written once; dT in, T out
+HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=4096)
+    p.add_argument("--warmup", type=int, default=256)
+    p.add_argument("--group", type=int, default=16, help="steps per hipGraph / all-gather bucket")
+    p.add_argument("--ring", type=int, default=64, help="distinct batches walked (HBM-cold)")
+    p.add_argument("--warm", action="store_true", help="re-use one batch (Infinity-Cache-warm)")
+    p.add_argument("--path", choices=["fused", "layers", "triplet"], default="fused",
+                   help="fused: one launch fwd+bwd (default); layers: Forward then Backward "
+                        "launches (the Layer API sequence); triplet: fused (q,a+,a-) step")
+    p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-variants", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=10.0)
+    return p.parse_args()
+
+
+class Batches:
+    """RING batches of synthetic GloVe-like pairs, generated on device (seed 1701)."""
+
+    def __init__(self, torch, ring, path, rank):
+        g = torch.Generator(device="cuda").manual_seed(1701 + rank)
+        mk = lambda *s: torch.randn(*s, device="cuda", generator=g)
+        self.q = mk(ring, N_PAIRS, 1, DIM) * 0.4          # N(0, 0.4^2): SURVEY 8(d)
+        self.a = mk(ring, N_PAIRS, 1, DIM) * 0.4
+        self.dT = mk(ring, N_PAIRS, 1, 1, 1)
+        self.dq = torch.empty_like(self.q)
+        self.da = torch.empty_like(self.a)
+        self.top_own = torch.empty(ring, N_PAIRS, 1, 1, 1, device="cuda")
+        if path == "triplet":
+            self.an = mk(ring, N_PAIRS, 1, DIM) * 0.4
+            self.y = (torch.rand(ring, N_PAIRS, 1, device="cuda", generator=g) < 0.8).float()
+            self.dan = torch.empty_like(self.a)
+            self.sneg = torch.empty(ring, N_PAIRS, 1, device="cuda")
+            self.loss = torch.empty(ring, 1, device="cuda")
+
+
+def make_step(capi, bt, path):
+    """step(slot, top): one pass over batch `slot`, scores written to `top`."""
+    if path == "fused":
+        def step(i, top):
+            capi.simcross_forward_backward(1, bt.q[i], bt.a[i], bt.dT[i], top, bt.dq[i], bt.da[i])
+    elif path == "layers":
+        def step(i, top):
+            capi.simcross_forward(1, bt.q[i], bt.a[i], top)
+            capi.simcross_backward(1, bt.q[i], bt.a[i], top, bt.dT[i], bt.dq[i], bt.da[i])
+    else:
+        def step(i, top):
+            capi.triplet_euclid_step(bt.q[i], bt.a[i], bt.an[i], bt.y[i], top.view(N_PAIRS, 1),
+                                     bt.sneg[i], bt.loss[i], bt.dq[i], bt.da[i], bt.dan[i],
+                                     margin=0.05)
+    return step
+
+
+def cpu_baseline(seconds):
+    """The oracle (CPU restatement of the reference loops), one thread, on a bounded
+    sample of the same workload: whole 4096x300 fwd+bwd passes for ~`seconds`."""
+    import numpy as np
+    from oracle import cpu_oracle as O
+    r = np.random.default_rng(1701)
+    q = (r.standard_normal((N_PAIRS, 1, DIM)) * 0.4).astype(np.float32)
+    a = (r.standard_normal((N_PAIRS, 1, DIM)) * 0.4).astype(np.float32)
+    dT = r.standard_normal((N_PAIRS, 1, 1, 1)).astype(np.float32)
+    t1 = O.time_simcross_fwd_bwd(1, q, a, dT, iters=2) / 2          # warm-up + estimate
+    iters = max(3, min(2000, int(seconds / max(t1, 1e-6))))
+    t = O.time_simcross_fwd_bwd(1, q, a, dT, iters=iters)
+    return {"value": N_PAIRS * iters / t, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": "%d fwd+bwd passes of SimCross Euclid (4096,1,300) fp32, oracle/mms_oracle.c "
+                      "-O2 single thread, %.1f s on %d-cpu host" % (iters, t, os.cpu_count() or 0)}
+
+
+def load_traffic(path_name):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/),
+    collected and corrected by tools/pmc_traffic.py; None when absent."""
+    f = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        d = json.load(open(f))
+        return d.get(path_name, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def run(args):
+    import torch
+    import torch.distributed as dist
+    from mms_answer_selection_amd import build, capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch --gpus %d with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if rank == 0:
+        build.build_all()
+    if world > 1:
+        dist.barrier()
+    capi.lib()
+
+    G = max(1, args.group)
+    ring = 1 if args.warm else max(G, args.ring // G * G)
+    bt = Batches(torch, ring, args.path, rank)
+    step = make_step(capi, bt, args.path)
+    ngroups = ring // G if not args.warm else 1
+
+    # score buckets: group g writes its G x 4096 scores into bucket g % 2
+    buckets = [torch.empty(G, N_PAIRS, 1, 1, 1, device="cuda") for _ in range(2)]
+    gathered = [torch.empty(world * G, N_PAIRS, 1, 1, 1, device="cuda") for _ in range(2)] if world > 1 else None
+    comm = torch.cuda.Stream() if world > 1 else None
+    bucket_free = [torch.cuda.Event() for _ in range(2)]   # gather of that bucket finished
+    main = torch.cuda.current_stream()
+
+    def group_body(gi):
+        b = buckets[gi % 2]
+        for s in range(G):
+            slot = 0 if args.warm else (gi % ngroups) * G + s
+            step(slot, b[s])
+
+    # eager warm-up of every code path (also fills caches / instantiates kernels)
+    for gi in range(max(2, min(ngroups, 4))):
+        group_body(gi)
+    torch.cuda.synchronize()
+
+    graphs = {}
+    use_graph = not args.no_graph
+    if use_graph:
+        # group gi uses ring slots (gi % ngroups) and bucket gi % 2 -> lcm(ngroups, 2) distinct graphs
+        period = ngroups if ngroups % 2 == 0 else ngroups * 2
+        cap = torch.cuda.Stream()
+        cap.wait_stream(main)
+        with torch.cuda.stream(cap):
+            for gi in range(period):
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph, stream=cap):
+                    group_body(gi)
+                graphs[gi] = gph
+        main.wait_stream(cap)
+        torch.cuda.synchronize()
+    else:
+        period = 1
+
+    def run_group(gi):
+        if world > 1:
+            main.wait_event(bucket_free[gi % 2])      # previous gather of this bucket done
+        if use_graph:
+            graphs[gi % period].replay()
+        else:
+            group_body(gi)
+        if world > 1:
+            comm.wait_stream(main)
+            with torch.cuda.stream(comm):
+                dist.all_gather_into_tensor(gathered[gi % 2].view(-1), buckets[gi % 2].view(-1))
+                bucket_free[gi % 2].record(comm)
+
+    def run_steps(k, g0):
+        full, rem = divmod(k, G)
+        for i in range(full):
+            run_group(g0 + i)
+        if rem:                                        # time EXACTLY k steps
+            b = buckets[(g0 + full) % 2]
+            if world > 1:
+                main.wait_event(bucket_free[(g0 + full) % 2])
+            for s in range(rem):
+                step(0 if args.warm else ((g0 + full) % ngroups) * G + s, b[s])
+            if world > 1:
+                comm.wait_stream(main)
+                with torch.cuda.stream(comm):
+                    dist.all_gather_into_tensor(gathered[(g0 + full) % 2].view(-1), b.view(-1))
+                    bucket_free[(g0 + full) % 2].record(comm)
+        return g0 + full + (1 if rem else 0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    g0 = run_steps(args.warmup, 0)
+    fence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(main)
+    run_steps(args.steps, g0)
+    e1.record(main)
+    fence()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    ev_ms = e0.elapsed_time(e1)
+
+    tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall = float(tmax.item())
+
+    out = None
+    if rank == 0:
+        launches_per_step = {"fused": 1, "layers": 2, "triplet": 2}[args.path]
+        step_us_ev = ev_ms * 1e3 / args.steps            # HIP events on the launch stream
+        achieved = B_UNFUSED / (step_us_ev * 1e-6) / 1e9 if args.path != "triplet" else None
+        value = world * N_PAIRS * args.steps / wall
+        kernel = {"fused": "euclid_rows_kernel<BWD=true> (SimCross Euclid fwd+bwd, one launch)",
+                  "layers": "euclid_rows_kernel<BWD=false> + euclid_rows_bwd_kernel",
+                  "triplet": "triplet_euclid_kernel + loss_finish_kernel"}[args.path]
+        out = {
+            "metric": "QA pairs/sec (fwd+bwd) at batch 4096, 300-d; % HBM roofline",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2: SimCross dist_mode=1 (Euclid) fwd+bwd, q,a (4096,1,300) fp32 per GPU",
+                       "pairs_per_gpu": N_PAIRS, "dim": DIM, "global_batch": world * N_PAIRS,
+                       "path": args.path, "launches_per_step": launches_per_step,
+                       "residency": "cache-warm (1 batch)" if args.warm else
+                                    "HBM-cold ring of %d batches (%.2f GiB)" % (ring, ring * 19.7e6 / 2**30),
+                       "hip_graph_group": G if use_graph else 0,
+                       "parallelism": "pair-sharded x%d%s" % (
+                           world, ", RCCL all-gather of scores per %d steps" % G if world > 1 else "")},
+        }
+        if achieved is not None:
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.path),
+                "kernel": kernel,
+                "algorithmic_bytes_per_launch": B_UNFUSED if args.path == "fused" else None,
+                "algorithmic_bytes_per_step": B_UNFUSED,
+                "fused_compulsory_bytes_per_step": B_FUSED if args.path == "fused" else None,
+                "frac_vs_fused_bytes": (B_FUSED / (step_us_ev * 1e-6) / 1e9 / HBM_PEAK_GBS
+                                        if args.path == "fused" else None),
+                "avg_step_us_hip_events": step_us_ev,
+                "note": "duration = HIP events over the timed region / steps on rank 0 "
+                        "(launch-to-launch, includes inter-kernel gaps)"}
+    if world > 1:
+        dist.barrier()
+
+    # side measurements on rank 0 at N=1 only (not part of the timed region above)
+    if rank == 0 and world == 1 and not args.no_variants:
+        out["variants"] = variants(torch, capi, args)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def variants(torch, capi, args):
+    """Short interleaved measurements of the other entry points / residency, same device."""
+    res = {}
+    K, G = 1024, 16
+    for name, path, ring in (("fused_cold", "fused", 64), ("fused_warm", "fused", 1),
+                             ("layers_cold", "layers", 64), ("layers_warm", "layers", 1),
+                             ("triplet_cold", "triplet", 48)):
+        if path == args.path and ((ring == 1) == args.warm):
+            continue
+        bt = Batches(torch, ring, path, 0)
+        step = make_step(capi, bt, path)
+        top = torch.empty(G, N_PAIRS, 1, 1, 1, device="cuda")
+        ng = max(1, ring // G)
+        graphs = []
+        for gi in range(ng):
+            for s in range(G):
+                step((gi * G + s) % ring, top[s])
+        torch.cuda.synchronize()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            for gi in range(ng):
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph, stream=cap):
+                    for s in range(G):
+                        step((gi * G + s) % ring, top[s])
+                graphs.append(gph)
+        torch.cuda.current_stream().wait_stream(cap)
+        for i in range(8):
+            graphs[i % ng].replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(K // G):
+            graphs[i % ng].replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / K
+        pairs = N_PAIRS
+        res[name] = {"us_per_step": us, "pairs_per_s": pairs / (us * 1e-6)}
+        if path != "triplet":
+            res[name]["frac_hbm_unfused_bytes"] = B_UNFUSED / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+        del bt, graphs
+        torch.cuda.empty_cache()
+    return res
+
+
+if __name__ == "__main__":
+    run(parse())

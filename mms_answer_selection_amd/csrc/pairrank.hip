@@ -10,6 +10,7 @@
 // Per-element values are bit-identical to the CPU code.  The loss scalar is a
 // fixed-shape tree sum (deterministic; the reference's 1-thread running sum
 // is not reproduced -- tests hold it to 1e-5 relative).
+#include "euclid_math.h"
 #include "mms_common.h"
 
 namespace mms {
@@ -132,17 +133,129 @@ int pairrank_backward(int count, float top_diff, const float* y, const float* or
 // ======================= fused (q, a+, a-) training step =====================
 // Euclidean SimCross on (q,a+) and (q,a-), PairRankLoss on the two score
 // columns, and the whole backward, in one launch (+ a one-block loss finish).
-// A workgroup owns ROWS triplets: q-a+ and q-a- live in LDS from the first
-// HBM read to the gradient write, so each input is read once and each
-// gradient written once.  One lane per (triplet, branch) walks d ascending
-// (reference order, sim_cross_layer.cpp:100-106).
-__device__ __forceinline__ void triplet_coef(float T, float g, float& c, double& den) {
-  c = g * T * T * T;                  // sim_cross_layer.cpp:216
-  den = (double)(T - 1.0f) + 1e-9;    // :217
+// Same wave-centric structure as euclid_rows_wave_kernel: a wave owns kTW = 2
+// triplets, issues all its 16-byte loads of q, a+, a- up front, keeps q-a+ and
+// q-a- in registers, and four lanes (2 triplets x 2 branches) walk the squares
+// d-ascending (reference order, sim_cross_layer.cpp:100-106).  Each input is
+// read once and each gradient written once.
+constexpr int kTW = 2;
+
+template <int NIT>
+__global__ __launch_bounds__(256) void triplet_wave_kernel(
+    int N, int D4, float margin, float s0, float s1, const float* __restrict__ q,
+    const float* __restrict__ ap, const float* __restrict__ an, const float* __restrict__ y,
+    float* __restrict__ s_pos, float* __restrict__ s_neg, float* __restrict__ partials,
+    float* __restrict__ dq, float* __restrict__ dap, float* __restrict__ dan) {
+  extern __shared__ float4 lds4[];               // [4 waves][2 branches][kTW * D4] squares
+  __shared__ float Ts[4][2][kTW];
+  __shared__ float cs[4][2][kTW];
+  __shared__ double dens[4][2][kTW];
+  __shared__ double rcps[4][2][kTW];
+  __shared__ float terms[4][kTW];
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + wave;
+  const int row0 = gw * kTW;
+  if (row0 >= N) return;
+  const int rows = min(kTW, N - row0);
+  const int n4 = rows * D4;
+  const size_t base4 = (size_t)row0 * D4;
+  const float4* q4 = reinterpret_cast<const float4*>(q) + base4;
+  const float4* p4 = reinterpret_cast<const float4*>(ap) + base4;
+  const float4* m4 = reinterpret_cast<const float4*>(an) + base4;
+  float4* sqp = lds4 + (size_t)wave * 2 * kTW * D4;
+  float4* sqn = sqp + kTW * D4;
+
+  float4 x[NIT], u[NIT], v[NIT], dp[NIT], dn[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane + 64 * it;
+    const int ii = i < n4 ? i : 0;
+    x[it] = q4[ii]; u[it] = p4[ii]; v[it] = m4[ii];
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane + 64 * it;
+    dp[it].x = x[it].x - u[it].x; dp[it].y = x[it].y - u[it].y;
+    dp[it].z = x[it].z - u[it].z; dp[it].w = x[it].w - u[it].w;
+    dn[it].x = x[it].x - v[it].x; dn[it].y = x[it].y - v[it].y;
+    dn[it].z = x[it].z - v[it].z; dn[it].w = x[it].w - v[it].w;
+    float4 a, b;
+    a.x = dp[it].x * dp[it].x; a.y = dp[it].y * dp[it].y;
+    a.z = dp[it].z * dp[it].z; a.w = dp[it].w * dp[it].w;
+    b.x = dn[it].x * dn[it].x; b.y = dn[it].y * dn[it].y;
+    b.z = dn[it].z * dn[it].z; b.w = dn[it].w * dn[it].w;
+    if (i < n4) { sqp[i] = a; sqn[i] = b; }
+  }
+  wave_lds_sync();
+
+  // lanes [0,kTW): positive branch of triplet `lane`; lanes [kTW,2kTW): negative.
+  if (lane < 2 * kTW) {
+    const int br = lane / kTW, r = lane % kTW;
+    if (r < rows) {
+      const float dist = chain_sum_lds((br ? sqn : sqp) + r * D4, D4);
+      const float T = 1.0f / (1.0f + sqrtf(dist));
+      Ts[wave][br][r] = T;
+      (br ? s_neg : s_pos)[row0 + r] = T;
+    }
+  }
+  wave_lds_sync();
+
+  if (lane < kTW) {
+    float t = 0.f;
+    if (lane < rows) {
+      const float yy = y[row0 + lane];
+      const float Tp = Ts[wave][0][lane], Tn = Ts[wave][1][lane];
+      const PairTerm p = pair_term(Tp, Tn, yy, margin);
+      float ga, gb;
+      pair_grad(yy, p.ordered, p.similar, s0, s1, ga, gb);
+      const EuclidCoef k0 = euclid_coef(Tp, ga), k1 = euclid_coef(Tn, gb);
+      cs[wave][0][lane] = k0.c; dens[wave][0][lane] = k0.den; rcps[wave][0][lane] = k0.rcp;
+      cs[wave][1][lane] = k1.c; dens[wave][1][lane] = k1.den; rcps[wave][1][lane] = k1.rcp;
+      t = p.term;
+    }
+    terms[wave][lane] = t;
+  }
+  wave_lds_sync();
+  if (lane == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < kTW; ++r) s += terms[wave][r];
+    partials[gw] = s;
+  }
+
+  // Layer-by-layer semantics: each SimCross backward produces dq_branch = 0 + tt and
+  // da = 0 + (-tt); Caffe's Split layer then adds the two dq_branch blobs.
+  float4* dq4 = reinterpret_cast<float4*>(dq) + base4;
+  float4* dp4 = reinterpret_cast<float4*>(dap) + base4;
+  float4* dn4 = reinterpret_cast<float4*>(dan) + base4;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane + 64 * it;
+    if (i >= n4) break;
+    const int r = i >= D4 ? 1 : 0;
+    EuclidCoef k0, k1;
+    k0.c = cs[wave][0][r]; k0.den = dens[wave][0][r]; k0.rcp = rcps[wave][0][r];
+    k1.c = cs[wave][1][r]; k1.den = dens[wave][1][r]; k1.rcp = rcps[wave][1][r];
+    float tp[4], tn[4];
+    tp[0] = euclid_tt(k0, dp[it].x); tp[1] = euclid_tt(k0, dp[it].y);
+    tp[2] = euclid_tt(k0, dp[it].z); tp[3] = euclid_tt(k0, dp[it].w);
+    tn[0] = euclid_tt(k1, dn[it].x); tn[1] = euclid_tt(k1, dn[it].y);
+    tn[2] = euclid_tt(k1, dn[it].z); tn[3] = euclid_tt(k1, dn[it].w);
+    float4 oq, op, on;
+    oq.x = (0.f + tp[0]) + (0.f + tn[0]); oq.y = (0.f + tp[1]) + (0.f + tn[1]);
+    oq.z = (0.f + tp[2]) + (0.f + tn[2]); oq.w = (0.f + tp[3]) + (0.f + tn[3]);
+    op.x = 0.f + (-tp[0]); op.y = 0.f + (-tp[1]); op.z = 0.f + (-tp[2]); op.w = 0.f + (-tp[3]);
+    on.x = 0.f + (-tn[0]); on.y = 0.f + (-tn[1]); on.z = 0.f + (-tn[2]); on.w = 0.f + (-tn[3]);
+    dq4[i] = oq;
+    dp4[i] = op;
+    dn4[i] = on;
+  }
 }
 
-template <int ROWS, int THREADS, bool VEC4>
-__global__ __launch_bounds__(THREADS) void triplet_euclid_kernel(
+// Generic fallback (any D / alignment): a workgroup owns ROWS triplets.
+template <int ROWS, int THREADS>
+__global__ __launch_bounds__(THREADS) void triplet_generic_kernel(
     int N, int D, float margin, float s0, float s1, const float* __restrict__ q,
     const float* __restrict__ ap, const float* __restrict__ an, const float* __restrict__ y,
     float* __restrict__ s_pos, float* __restrict__ s_neg, float* __restrict__ partials,
@@ -159,53 +272,24 @@ __global__ __launch_bounds__(THREADS) void triplet_euclid_kernel(
   const int rows = min(ROWS, N - row0);
   const size_t base = (size_t)row0 * D;
   const int total = rows * D;
-
-  if (VEC4) {
-    const float4* q4 = reinterpret_cast<const float4*>(q + base);
-    const float4* p4 = reinterpret_cast<const float4*>(ap + base);
-    const float4* n4 = reinterpret_cast<const float4*>(an + base);
-    float4* dp4 = reinterpret_cast<float4*>(dpos);
-    float4* dn4 = reinterpret_cast<float4*>(dneg);
-    for (int i = threadIdx.x; i < (total >> 2); i += THREADS) {
-      const float4 x = q4[i], u = p4[i], v = n4[i];
-      float4 a, b;
-      a.x = x.x - u.x; a.y = x.y - u.y; a.z = x.z - u.z; a.w = x.w - u.w;
-      b.x = x.x - v.x; b.y = x.y - v.y; b.z = x.z - v.z; b.w = x.w - v.w;
-      dp4[i] = a;
-      dn4[i] = b;
-    }
-  } else {
-    for (int i = threadIdx.x; i < total; i += THREADS) {
-      const float x = q[base + i];
-      dpos[i] = x - ap[base + i];
-      dneg[i] = x - an[base + i];
-    }
+  for (int i = threadIdx.x; i < total; i += THREADS) {
+    const float x = q[base + i];
+    dpos[i] = x - ap[base + i];
+    dneg[i] = x - an[base + i];
   }
   __syncthreads();
-
-  // lanes [0,ROWS): positive branch; lanes [ROWS,2*ROWS): negative branch.
   if (threadIdx.x < 2 * ROWS) {
     const int br = threadIdx.x / ROWS, r = threadIdx.x % ROWS;
     if (r < rows) {
       const float* src = (br ? dneg : dpos) + r * D;
       float dist = 0.f;
-      if (VEC4) {
-        const float4* r4 = reinterpret_cast<const float4*>(src);
-#pragma unroll 4
-        for (int d = 0; d < (D >> 2); ++d) {
-          const float4 v = r4[d];
-          dist += v.x * v.x; dist += v.y * v.y; dist += v.z * v.z; dist += v.w * v.w;
-        }
-      } else {
-        for (int d = 0; d < D; ++d) dist += src[d] * src[d];
-      }
+      for (int d = 0; d < D; ++d) dist += src[d] * src[d];
       const float T = 1.0f / (1.0f + sqrtf(dist));
       Ts[br][r] = T;
       (br ? s_neg : s_pos)[row0 + r] = T;
     }
   }
   __syncthreads();
-
   if (threadIdx.x < ROWS) {
     const int r = threadIdx.x;
     float t = 0.f;
@@ -214,67 +298,37 @@ __global__ __launch_bounds__(THREADS) void triplet_euclid_kernel(
       const PairTerm p = pair_term(Ts[0][r], Ts[1][r], yy, margin);
       float ga, gb;
       pair_grad(yy, p.ordered, p.similar, s0, s1, ga, gb);
-      float c; double den;
-      triplet_coef(Ts[0][r], ga, c, den); cs[0][r] = c; dens[0][r] = den;
-      triplet_coef(Ts[1][r], gb, c, den); cs[1][r] = c; dens[1][r] = den;
+      const EuclidCoef k0 = euclid_coef(Ts[0][r], ga), k1 = euclid_coef(Ts[1][r], gb);
+      cs[0][r] = k0.c; dens[0][r] = k0.den;
+      cs[1][r] = k1.c; dens[1][r] = k1.den;
       t = p.term;
     }
     terms[r] = t;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    // same association as the wave kernel's (pair partials, then the finish tree)
+    // is not required: the loss is held to 1e-5, not bitwise.
     float s = 0.f;
-#pragma unroll
     for (int r = 0; r < ROWS; ++r) s += terms[r];
     partials[blockIdx.x] = s;
   }
-
-  // Gradients.  Layer-by-layer semantics: each SimCross backward produces
-  // dq_branch = 0 + tt, da = 0 + (-tt); Caffe's Split layer then adds the two
-  // dq_branch blobs (split_layer.cpp: caffe_add(bottom_diff = top0 + top1)).
-  if (VEC4) {
-    const int D4 = D >> 2;
-    const float4* dp4 = reinterpret_cast<const float4*>(dpos);
-    const float4* dn4 = reinterpret_cast<const float4*>(dneg);
-    float4* dq4 = reinterpret_cast<float4*>(dq + base);
-    float4* dap4 = reinterpret_cast<float4*>(dap + base);
-    float4* dan4 = reinterpret_cast<float4*>(dan + base);
-    for (int i = threadIdx.x; i < (total >> 2); i += THREADS) {
-      const int r = i / D4;
-      const float c0 = cs[0][r], c1 = cs[1][r];
-      const double e0 = dens[0][r], e1 = dens[1][r];
-      const float4 a = dp4[i], b = dn4[i];
-      float tp[4], tn[4];
-      tp[0] = (float)((double)(c0 * a.x) / e0); tp[1] = (float)((double)(c0 * a.y) / e0);
-      tp[2] = (float)((double)(c0 * a.z) / e0); tp[3] = (float)((double)(c0 * a.w) / e0);
-      tn[0] = (float)((double)(c1 * b.x) / e1); tn[1] = (float)((double)(c1 * b.y) / e1);
-      tn[2] = (float)((double)(c1 * b.z) / e1); tn[3] = (float)((double)(c1 * b.w) / e1);
-      float4 oq, op, on;
-      oq.x = (0.f + tp[0]) + (0.f + tn[0]); oq.y = (0.f + tp[1]) + (0.f + tn[1]);
-      oq.z = (0.f + tp[2]) + (0.f + tn[2]); oq.w = (0.f + tp[3]) + (0.f + tn[3]);
-      op.x = 0.f + (-tp[0]); op.y = 0.f + (-tp[1]); op.z = 0.f + (-tp[2]); op.w = 0.f + (-tp[3]);
-      on.x = 0.f + (-tn[0]); on.y = 0.f + (-tn[1]); on.z = 0.f + (-tn[2]); on.w = 0.f + (-tn[3]);
-      dq4[i] = oq;
-      dap4[i] = op;
-      dan4[i] = on;
-    }
-  } else {
-    for (int i = threadIdx.x; i < total; i += THREADS) {
-      const int r = i / D;
-      const float tp = (float)((double)(cs[0][r] * dpos[i]) / dens[0][r]);
-      const float tn = (float)((double)(cs[1][r] * dneg[i]) / dens[1][r]);
-      dq[base + i] = (0.f + tp) + (0.f + tn);
-      dap[base + i] = 0.f + (-tp);
-      dan[base + i] = 0.f + (-tn);
-    }
+  for (int i = threadIdx.x; i < total; i += THREADS) {
+    const int r = i / D;
+    const float tp = euclid_tt_exact(cs[0][r], dens[0][r], dpos[i]);
+    const float tn = euclid_tt_exact(cs[1][r], dens[1][r], dneg[i]);
+    dq[base + i] = (0.f + tp) + (0.f + tn);
+    dap[base + i] = 0.f + (-tp);
+    dan[base + i] = 0.f + (-tn);
   }
 }
 
 constexpr int kTripRows = 8;
 constexpr int kTripThreads = 256;
 
+// one float per wave-pair of triplets (wave kernel) -- the generic kernel needs fewer
 size_t triplet_workspace_bytes(int N) {
-  return (size_t)((N + kTripRows - 1) / kTripRows) * sizeof(float);
+  return (size_t)((N + kTW - 1) / kTW) * sizeof(float);
 }
 
 int triplet_euclid_step(int N, int D, float margin, float loss_weight, const float* q,
@@ -282,24 +336,38 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
                         float* s_neg, float* loss, float* dq, float* dap, float* dan, void* ws,
                         size_t ws_bytes, hipStream_t s) {
   if (N == 0) return MMS_OK;
-  const size_t lds = 2 * (size_t)kTripRows * D * sizeof(float);
-  if (lds > 96 * 1024) return MMS_ERR_UNSUPPORTED;
   if (ws == nullptr || ws_bytes < triplet_workspace_bytes(N)) return MMS_ERR_WORKSPACE;
-  const int blocks = (N + kTripRows - 1) / kTripRows;
   const float scale = loss_weight / (float)N;  // pair_rank_loss_layer.cpp:64, count = N*1
   const float s0 = -1.0f * scale, s1 = 1.0f * scale;
   float* partials = static_cast<float*>(ws);
   const bool v = (D % 4 == 0) && aligned16(q) && aligned16(ap) && aligned16(an) &&
                  aligned16(dq) && aligned16(dap) && aligned16(dan);
-  if (v)
-    hipLaunchKernelGGL((triplet_euclid_kernel<kTripRows, kTripThreads, true>), dim3(blocks),
+  const int nit = (kTW * (D / 4) + 63) / 64;
+  int nparts;
+  if (v && nit <= 8) {
+    const int D4 = D / 4;
+    nparts = (N + kTW - 1) / kTW;
+    const unsigned grid = (unsigned)((nparts + 3) / 4);
+    const size_t lds = (size_t)4 * 2 * kTW * D4 * sizeof(float4);
+    switch (nit) {
+#define MMS_NIT_CASE(n)                                                                        \
+  case n:                                                                                      \
+    hipLaunchKernelGGL((triplet_wave_kernel<n>), dim3(grid), dim3(256), lds, s, N, D4, margin, \
+                       s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan);            \
+    break;
+      MMS_NIT_CASE(1) MMS_NIT_CASE(2) MMS_NIT_CASE(3) MMS_NIT_CASE(4)
+      MMS_NIT_CASE(5) MMS_NIT_CASE(6) MMS_NIT_CASE(7) MMS_NIT_CASE(8)
+#undef MMS_NIT_CASE
+    }
+  } else {
+    const size_t lds = 2 * (size_t)kTripRows * D * sizeof(float);
+    if (lds > 96 * 1024) return MMS_ERR_UNSUPPORTED;
+    nparts = (N + kTripRows - 1) / kTripRows;
+    hipLaunchKernelGGL((triplet_generic_kernel<kTripRows, kTripThreads>), dim3(nparts),
                        dim3(kTripThreads), lds, s, N, D, margin, s0, s1, q, ap, an, y, s_pos,
                        s_neg, partials, dq, dap, dan);
-  else
-    hipLaunchKernelGGL((triplet_euclid_kernel<kTripRows, kTripThreads, false>), dim3(blocks),
-                       dim3(kTripThreads), lds, s, N, D, margin, s0, s1, q, ap, an, y, s_pos,
-                       s_neg, partials, dq, dap, dan);
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kPairThreads), 0, s, partials, blocks, N,
+  }
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kPairThreads), 0, s, partials, nparts, N,
                      loss);
   return launch_status();
 }

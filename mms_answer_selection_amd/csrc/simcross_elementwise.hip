@@ -21,26 +21,115 @@
 //
 // Compiled with -ffp-contract=off: the reference CPU build has no FMA
 // contraction, so mul and add must round separately to match it bitwise.
+#include "euclid_math.h"
 #include "mms_common.h"
 
 namespace mms {
 
-// ---- Euclidean backward coefficient (sim_cross_layer.cpp:216-217) ----------
-// numerator  dT*T*T*T*(q-a): float, left to right.
-// divisor    (T - 1) in float, + 1e-9 in double.  Quotient in double -> float.
-__device__ __forceinline__ void euclid_coef(float T, float g, float& c, double& den) {
-  c = g * T * T * T;
-  den = (double)(T - 1.0f) + 1e-9;
-}
-__device__ __forceinline__ float euclid_tt(float c, double den, float diff) {
-  return (float)((double)(c * diff) / den);
-}
-
 // =============================== rows geometry ==============================
 
+// ---- wave-centric kernel (the fast path) ------------------------------------
+// A wave owns RW = 2 consecutive pairs (RW*D/4 float4 per operand); the four
+// waves of a workgroup are independent (no workgroup barrier).  Timeline of
+// one wave:
+//   1. ALL its 16-byte loads of q and a are issued back to back (NIT per
+//      operand per lane, predicated) -- nothing waits inside a loop;
+//   2. diff = q-a stays in registers; diff^2 goes to the wave's LDS slice;
+//   3. lanes 0..RW-1 each walk one pair's squares d-ascending with adds only
+//      (LDS reads batched 8 x 16 B ahead): the reference's summation order;
+//   4. those lanes publish T and the backward coefficients through LDS;
+//   5. every lane turns its register-resident diffs into dq / da and stores
+//      16 bytes per lane.
+// FWD only stops after 3; BWD only skips 2-3 and reads T from memory.
+constexpr int kRW = 2;
+
+template <int NIT, bool FWD, bool BWD>
+__global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
+    const float* __restrict__ q, const float* __restrict__ a,
+    const float* __restrict__ top_in, const float* __restrict__ top_diff,
+    float* __restrict__ top_out, float* __restrict__ dq, float* __restrict__ da, int N,
+    int D4) {
+  extern __shared__ float4 lds4[];               // [4 waves][kRW * D4] squares
+  __shared__ float cs[4][kRW];
+  __shared__ double dens[4][kRW];
+  __shared__ double rcps[4][kRW];
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + wave) * kRW;
+  if (row0 >= N) return;                         // whole wave leaves; no block barrier below
+  const int rows = min(kRW, N - row0);
+  const int n4 = rows * D4;
+  const size_t base4 = (size_t)row0 * D4;
+  const float4* q4 = reinterpret_cast<const float4*>(q) + base4;
+  const float4* a4 = reinterpret_cast<const float4*>(a) + base4;
+  float4* sq4 = lds4 + (size_t)wave * kRW * D4;
+
+  float4 x[NIT], y[NIT], df[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane + 64 * it;
+    const int ii = i < n4 ? i : 0;               // clamp: keep the load unconditional
+    x[it] = q4[ii];
+    y[it] = a4[ii];
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    df[it].x = x[it].x - y[it].x; df[it].y = x[it].y - y[it].y;
+    df[it].z = x[it].z - y[it].z; df[it].w = x[it].w - y[it].w;
+    if (FWD) {
+      const int i = lane + 64 * it;
+      float4 s;
+      s.x = df[it].x * df[it].x; s.y = df[it].y * df[it].y;
+      s.z = df[it].z * df[it].z; s.w = df[it].w * df[it].w;
+      if (i < n4) sq4[i] = s;
+    }
+  }
+  wave_lds_sync();
+
+  if (lane < rows) {
+    float T;
+    if (FWD) {
+      const float dist = chain_sum_lds(sq4 + lane * D4, D4);
+      T = 1.0f / (1.0f + sqrtf(dist));          // :106-107
+      top_out[row0 + lane] = T;
+    } else {
+      T = top_in[row0 + lane];
+    }
+    if (BWD) {
+      const EuclidCoef k = euclid_coef(T, top_diff[row0 + lane]);
+      cs[wave][lane] = k.c;
+      dens[wave][lane] = k.den;
+      rcps[wave][lane] = k.rcp;
+    }
+  }
+  if (!BWD) return;
+  wave_lds_sync();
+
+  float4* dq4 = reinterpret_cast<float4*>(dq) + base4;
+  float4* da4 = reinterpret_cast<float4*>(da) + base4;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane + 64 * it;
+    if (i >= n4) break;
+    const int r = i >= D4 ? 1 : 0;              // kRW == 2
+    EuclidCoef k;
+    k.c = cs[wave][r]; k.den = dens[wave][r]; k.rcp = rcps[wave][r];
+    float4 t;
+    t.x = euclid_tt(k, df[it].x); t.y = euclid_tt(k, df[it].y);
+    t.z = euclid_tt(k, df[it].z); t.w = euclid_tt(k, df[it].w);
+    // dq = 0 + tt ; da = 0 + (-tt)   (:176-177 zero, :219-220 accumulate once)
+    float4 o0, o1;
+    o0.x = 0.f + t.x; o0.y = 0.f + t.y; o0.z = 0.f + t.z; o0.w = 0.f + t.w;
+    o1.x = 0.f + (-t.x); o1.y = 0.f + (-t.y); o1.z = 0.f + (-t.z); o1.w = 0.f + (-t.w);
+    dq4[i] = o0;
+    da4[i] = o1;
+  }
+}
+
+// ---- generic fallback (any D, any alignment): workgroup of ROWS pairs --------
 // Forward (BWD=false) or forward+backward (BWD=true) for W1=W2=1, Euclidean.
 // LDS: diff[ROWS*D] floats (dynamic) + per-row coefficient slots.
-template <int ROWS, int THREADS, bool VEC4, bool BWD>
+template <int ROWS, int THREADS, bool BWD>
 __global__ __launch_bounds__(THREADS) void euclid_rows_kernel(
     const float* __restrict__ q, const float* __restrict__ a,
     const float* __restrict__ top_diff, float* __restrict__ top,
@@ -55,115 +144,45 @@ __global__ __launch_bounds__(THREADS) void euclid_rows_kernel(
   const size_t base = (size_t)row0 * D;
   const int total = rows * D;
 
-  if (VEC4) {
-    const float4* q4 = reinterpret_cast<const float4*>(q + base);
-    const float4* a4 = reinterpret_cast<const float4*>(a + base);
-    float4* d4 = reinterpret_cast<float4*>(diff);
-    for (int i = threadIdx.x; i < (total >> 2); i += THREADS) {
-      const float4 x = q4[i], y = a4[i];
-      float4 d;
-      d.x = x.x - y.x; d.y = x.y - y.y; d.z = x.z - y.z; d.w = x.w - y.w;
-      d4[i] = d;
-    }
-  } else {
-    for (int i = threadIdx.x; i < total; i += THREADS) diff[i] = q[base + i] - a[base + i];
-  }
+  for (int i = threadIdx.x; i < total; i += THREADS) diff[i] = q[base + i] - a[base + i];
   __syncthreads();
 
   // One lane per pair: the reference's d-ascending fp32 chain (:100-106).
   if (threadIdx.x < rows) {
     const float* r = diff + threadIdx.x * D;
     float dist = 0.f;
-    if (VEC4) {
-      const float4* r4 = reinterpret_cast<const float4*>(r);
-#pragma unroll 4
-      for (int d = 0; d < (D >> 2); ++d) {
-        const float4 v = r4[d];
-        dist += v.x * v.x; dist += v.y * v.y; dist += v.z * v.z; dist += v.w * v.w;
-      }
-    } else {
-      for (int d = 0; d < D; ++d) dist += r[d] * r[d];
-    }
+    for (int d = 0; d < D; ++d) dist += r[d] * r[d];
     dist = sqrtf(dist);
     const float T = 1.0f / (1.0f + dist);
     top[row0 + threadIdx.x] = T;
     if (BWD) {
-      float c; double den;
-      euclid_coef(T, top_diff[row0 + threadIdx.x], c, den);
-      cs[threadIdx.x] = c;
-      dens[threadIdx.x] = den;
+      const EuclidCoef k = euclid_coef(T, top_diff[row0 + threadIdx.x]);
+      cs[threadIdx.x] = k.c;
+      dens[threadIdx.x] = k.den;
     }
   }
   if (!BWD) return;
   __syncthreads();
-
-  // dq = 0 + tt ; da = 0 + (-tt)   (:176-177 zero, :219-220 accumulate once)
-  if (VEC4) {
-    const int D4 = D >> 2;
-    const float4* d4 = reinterpret_cast<const float4*>(diff);
-    float4* dq4 = reinterpret_cast<float4*>(dq + base);
-    float4* da4 = reinterpret_cast<float4*>(da + base);
-    for (int i = threadIdx.x; i < (total >> 2); i += THREADS) {
-      const int r = i / D4;
-      const float c = cs[r];
-      const double den = dens[r];
-      const float4 d = d4[i];
-      float4 t;
-      t.x = euclid_tt(c, den, d.x); t.y = euclid_tt(c, den, d.y);
-      t.z = euclid_tt(c, den, d.z); t.w = euclid_tt(c, den, d.w);
-      float4 o0, o1;
-      o0.x = 0.f + t.x; o0.y = 0.f + t.y; o0.z = 0.f + t.z; o0.w = 0.f + t.w;
-      o1.x = 0.f + (-t.x); o1.y = 0.f + (-t.y); o1.z = 0.f + (-t.z); o1.w = 0.f + (-t.w);
-      dq4[i] = o0;
-      da4[i] = o1;
-    }
-  } else {
-    for (int i = threadIdx.x; i < total; i += THREADS) {
-      const int r = i / D;
-      const float t = euclid_tt(cs[r], dens[r], diff[i]);
-      dq[base + i] = 0.f + t;
-      da[base + i] = 0.f + (-t);
-    }
+  for (int i = threadIdx.x; i < total; i += THREADS) {
+    const int r = i / D;
+    const float t = euclid_tt_exact(cs[r], dens[r], diff[i]);
+    dq[base + i] = 0.f + t;
+    da[base + i] = 0.f + (-t);
   }
 }
 
-// Backward alone for W1=W2=1, Euclidean: pure streaming, one 16-byte access
-// per operand per lane.
-template <bool VEC4>
+// Backward alone, generic fallback: pure streaming.
 __global__ __launch_bounds__(256) void euclid_rows_bwd_kernel(
     const float* __restrict__ q, const float* __restrict__ a,
     const float* __restrict__ top, const float* __restrict__ top_diff,
-    float* __restrict__ dq, float* __restrict__ da, long long total, int D) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  if (VEC4) {
-    const int D4 = D >> 2;
-    const float4* q4 = reinterpret_cast<const float4*>(q);
-    const float4* a4 = reinterpret_cast<const float4*>(a);
-    float4* dq4 = reinterpret_cast<float4*>(dq);
-    float4* da4 = reinterpret_cast<float4*>(da);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (total >> 2); i += stride) {
-      const long long r = i / D4;
-      float c; double den;
-      euclid_coef(top[r], top_diff[r], c, den);
-      const float4 x = q4[i], y = a4[i];
-      float4 t;
-      t.x = euclid_tt(c, den, x.x - y.x); t.y = euclid_tt(c, den, x.y - y.y);
-      t.z = euclid_tt(c, den, x.z - y.z); t.w = euclid_tt(c, den, x.w - y.w);
-      float4 o0, o1;
-      o0.x = 0.f + t.x; o0.y = 0.f + t.y; o0.z = 0.f + t.z; o0.w = 0.f + t.w;
-      o1.x = 0.f + (-t.x); o1.y = 0.f + (-t.y); o1.z = 0.f + (-t.z); o1.w = 0.f + (-t.w);
-      dq4[i] = o0;
-      da4[i] = o1;
-    }
-  } else {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-      const long long r = i / D;
-      float c; double den;
-      euclid_coef(top[r], top_diff[r], c, den);
-      const float t = euclid_tt(c, den, q[i] - a[i]);
-      dq[i] = 0.f + t;
-      da[i] = 0.f + (-t);
-    }
+    float* __restrict__ dq, float* __restrict__ da, int total, int D) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int r = i / D;
+    const EuclidCoef k = euclid_coef(top[r], top_diff[r]);
+    const float t = euclid_tt_exact(k.c, k.den, q[i] - a[i]);
+    dq[i] = 0.f + t;
+    da[i] = 0.f + (-t);
   }
 }
 
@@ -370,9 +389,8 @@ __global__ __launch_bounds__(256) void cross_bwd_kernel(
     float acc = 0.f;
     if (MODE == 1) {
       for (int k = 0; k < W2; ++k) {
-        float c; double den;
-        euclid_coef(Tn[j * W2 + k], gn[j * W2 + k], c, den);
-        acc += euclid_tt(c, den, qv - an[(size_t)k * D + d]);
+        const EuclidCoef kc = euclid_coef(Tn[j * W2 + k], gn[j * W2 + k]);
+        acc += euclid_tt_exact(kc.c, kc.den, qv - an[(size_t)k * D + d]);
       }
     } else {
       const float nrm0 = n0n[j];
@@ -390,9 +408,8 @@ __global__ __launch_bounds__(256) void cross_bwd_kernel(
     float acc = 0.f;
     if (MODE == 1) {
       for (int j = 0; j < W1; ++j) {
-        float c; double den;
-        euclid_coef(Tn[j * W2 + k], gn[j * W2 + k], c, den);
-        acc += -euclid_tt(c, den, qn[(size_t)j * D + d] - av);
+        const EuclidCoef kc = euclid_coef(Tn[j * W2 + k], gn[j * W2 + k]);
+        acc += -euclid_tt_exact(kc.c, kc.den, qn[(size_t)j * D + d] - av);
       }
     } else {
       const float nrm1 = n1n[k];
@@ -430,17 +447,44 @@ static void launch_cross_fwd(const float* q, const float* a, const float* n0,
 #undef MMS_CROSS_CASE
 }
 
-constexpr int kRows = 8;       // pairs per workgroup in the rows kernels
+constexpr int kRows = 8;       // pairs per workgroup in the generic rows kernels
 constexpr int kRowsThreads = 256;
 
+static bool all_aligned16(const void* p0, const void* p1, const void* p2, const void* p3) {
+  return aligned16(p0) && aligned16(p1) && (!p2 || aligned16(p2)) && (!p3 || aligned16(p3));
+}
 static bool vec4_ok(int D, const void* p0, const void* p1, const void* p2, const void* p3) {
-  return (D % 4 == 0) && aligned16(p0) && aligned16(p1) && (!p2 || aligned16(p2)) &&
-         (!p3 || aligned16(p3));
+  return (D % 4 == 0) && all_aligned16(p0, p1, p2, p3);
 }
 
-// LDS the rows kernel needs; falls back to the cross kernels above ~64 KB.
+// generic rows kernels: LDS needed; fall back to the cross kernels above ~64 KB.
 static size_t rows_lds_bytes(int D) { return (size_t)kRows * D * sizeof(float); }
 static bool rows_fit(int D) { return rows_lds_bytes(D) <= 64 * 1024; }
+
+// wave kernel: NIT = ceil(kRW * D/4 / 64) 16-byte loads per operand per lane.
+static int wave_nit(int D) { return (kRW * (D / 4) + 63) / 64; }
+static bool wave_ok(int D, const void* p0, const void* p1, const void* p2, const void* p3) {
+  return vec4_ok(D, p0, p1, p2, p3) && wave_nit(D) <= 8;
+}
+
+template <bool FWD, bool BWD>
+static void launch_rows_wave(const float* q, const float* a, const float* top_in,
+                             const float* top_diff, float* top_out, float* dq, float* da, int N,
+                             int D, hipStream_t s) {
+  const int D4 = D / 4;
+  const unsigned grid = (unsigned)((N + 4 * kRW - 1) / (4 * kRW));
+  const size_t lds = FWD ? (size_t)4 * kRW * D4 * sizeof(float4) : 0;
+  switch (wave_nit(D)) {
+#define MMS_NIT_CASE(n)                                                                      \
+  case n:                                                                                    \
+    hipLaunchKernelGGL((euclid_rows_wave_kernel<n, FWD, BWD>), dim3(grid), dim3(256), lds, s, \
+                       q, a, top_in, top_diff, top_out, dq, da, N, D4);                      \
+    break;
+    MMS_NIT_CASE(1) MMS_NIT_CASE(2) MMS_NIT_CASE(3) MMS_NIT_CASE(4)
+    MMS_NIT_CASE(5) MMS_NIT_CASE(6) MMS_NIT_CASE(7) MMS_NIT_CASE(8)
+#undef MMS_NIT_CASE
+  }
+}
 
 int simcross_elementwise_forward(int mode, int N, int W1, int W2, int D,
                                  const float* q, const float* a, float* top,
@@ -448,16 +492,13 @@ int simcross_elementwise_forward(int mode, int N, int W1, int W2, int D,
   if (N == 0) return MMS_OK;
   const bool rows = (W1 == 1 && W2 == 1);
   if (mode == 1) {
-    if (rows && rows_fit(D)) {
+    if (rows && wave_ok(D, q, a, nullptr, nullptr)) {
+      launch_rows_wave<true, false>(q, a, nullptr, nullptr, top, nullptr, nullptr, N, D, s);
+    } else if (rows && rows_fit(D)) {
       const unsigned grid = (N + kRows - 1) / kRows;
-      if (vec4_ok(D, q, a, nullptr, nullptr))
-        hipLaunchKernelGGL((euclid_rows_kernel<kRows, kRowsThreads, true, false>), dim3(grid),
-                           dim3(kRowsThreads), rows_lds_bytes(D), s, q, a, nullptr, top,
-                           nullptr, nullptr, N, D);
-      else
-        hipLaunchKernelGGL((euclid_rows_kernel<kRows, kRowsThreads, false, false>), dim3(grid),
-                           dim3(kRowsThreads), rows_lds_bytes(D), s, q, a, nullptr, top,
-                           nullptr, nullptr, N, D);
+      hipLaunchKernelGGL((euclid_rows_kernel<kRows, kRowsThreads, false>), dim3(grid),
+                         dim3(kRowsThreads), rows_lds_bytes(D), s, q, a, nullptr, top, nullptr,
+                         nullptr, N, D);
     } else {
       launch_cross_fwd<1>(q, a, nullptr, nullptr, top, N, W1, W2, D, s);
     }
@@ -488,17 +529,15 @@ int simcross_elementwise_backward(int mode, int N, int W1, int W2, int D,
   if (N == 0) return MMS_OK;
   const bool rows = (W1 == 1 && W2 == 1);
   if (rows && mode == 1) {
-    const long long total = (long long)N * D;
-    const bool v = vec4_ok(D, q, a, dq, da);
-    const long long items = v ? total / 4 : total;
-    long long blocks = (items + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    if (v)
-      hipLaunchKernelGGL((euclid_rows_bwd_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s,
-                         q, a, top, top_diff, dq, da, total, D);
-    else
-      hipLaunchKernelGGL((euclid_rows_bwd_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s,
-                         q, a, top, top_diff, dq, da, total, D);
+    if (wave_ok(D, q, a, dq, da)) {
+      launch_rows_wave<false, true>(q, a, top, top_diff, nullptr, dq, da, N, D, s);
+    } else {
+      const int total = N * D;
+      int blocks = (total + 255) / 256;
+      if (blocks > 256 * 16) blocks = 256 * 16;
+      hipLaunchKernelGGL(euclid_rows_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q, a,
+                         top, top_diff, dq, da, total, D);
+    }
   } else if (rows && mode == 0) {
     const unsigned grid = (N + 3) / 4;
     if (vec4_ok(D, q, a, dq, da))
@@ -528,14 +567,14 @@ int simcross_elementwise_forward_backward(int mode, int N, int W1, int W2, int D
                                           float* da, hipStream_t s) {
   if (N == 0) return MMS_OK;
   const bool rows = (W1 == 1 && W2 == 1);
+  if (rows && mode == 1 && wave_ok(D, q, a, dq, da)) {
+    launch_rows_wave<true, true>(q, a, nullptr, top_diff, top, dq, da, N, D, s);
+    return launch_status();
+  }
   if (rows && mode == 1 && rows_fit(D)) {
     const unsigned grid = (N + kRows - 1) / kRows;
-    if (vec4_ok(D, q, a, dq, da))
-      hipLaunchKernelGGL((euclid_rows_kernel<kRows, kRowsThreads, true, true>), dim3(grid),
-                         dim3(kRowsThreads), rows_lds_bytes(D), s, q, a, top_diff, top, dq, da, N, D);
-    else
-      hipLaunchKernelGGL((euclid_rows_kernel<kRows, kRowsThreads, false, true>), dim3(grid),
-                         dim3(kRowsThreads), rows_lds_bytes(D), s, q, a, top_diff, top, dq, da, N, D);
+    hipLaunchKernelGGL((euclid_rows_kernel<kRows, kRowsThreads, true>), dim3(grid),
+                       dim3(kRowsThreads), rows_lds_bytes(D), s, q, a, top_diff, top, dq, da, N, D);
     return launch_status();
   }
   if (rows && mode == 0) {
