@@ -1,0 +1,67 @@
+/*
+ * include/mms_layer.h -- C handle API over the C++ mirror of the Caffe
+ * Layer/Blob interface (libmms_caffe.so, csrc/caffe_api.hpp + caffe_layers.cpp).
+ *
+ * The C++ classes are what a Caffe build would use directly;
+ * this handle API exists so that non-C++ hosts -- the pytest suite, a pycaffe
+ * style binding -- can drive the same objects:
+ *   create a layer from prototxt text through LayerRegistry::CreateLayer
+ *   (include/caffe/layer_factory.hpp:56-84), wire Blobs, SetUp, Forward, Backward.
+ *
+ * Error behaviour is Caffe's: a failed CHECK prints the message and abort()s
+ * (glog LOG(FATAL), include/caffe/util/device_alternate.hpp:48-76).  Only
+ * mms_layer_create reports a prototxt syntax error by returning NULL.
+ */
+#ifndef MMS_LAYER_H_
+#define MMS_LAYER_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mms_blob mms_blob_t;
+typedef struct mms_layer mms_layer_t;
+
+/* Blob<float> (include/caffe/blob.hpp:24-277) */
+mms_blob_t* mms_blob_create(const int* shape, int num_axes);
+void mms_blob_destroy(mms_blob_t* b);
+void mms_blob_reshape(mms_blob_t* b, const int* shape, int num_axes);
+int mms_blob_num_axes(const mms_blob_t* b);
+int mms_blob_shape(const mms_blob_t* b, int axis);
+int mms_blob_count(const mms_blob_t* b);
+/* which = 0 data, 1 diff.  The *_cpu_* / *_gpu_* pairs move the SyncedMemory
+ * head exactly like Blob::cpu_data()/mutable_gpu_diff() etc. */
+const float* mms_blob_cpu(mms_blob_t* b, int which);
+float* mms_blob_mutable_cpu(mms_blob_t* b, int which);
+const float* mms_blob_gpu(mms_blob_t* b, int which);
+float* mms_blob_mutable_gpu(mms_blob_t* b, int which);
+
+/* Layer<float> (include/caffe/layer.hpp:32-445).  `prototxt` is one
+ * `layer { ... }` message in protobuf text format, e.g.
+ *   layer { name: "sim" type: "SimCross" bottom: "q" bottom: "a" top: "s"
+ *           sim_cross_param { dist_mode: 2 mesure_count: 4 } }            */
+mms_layer_t* mms_layer_create(const char* prototxt, char* err, int err_len);
+void mms_layer_destroy(mms_layer_t* l);
+const char* mms_layer_type(const mms_layer_t* l);
+void mms_layer_setup(mms_layer_t* l, mms_blob_t* const* bottom, int nbottom,
+                     mms_blob_t* const* top, int ntop);
+float mms_layer_forward(mms_layer_t* l, mms_blob_t* const* bottom, int nbottom,
+                        mms_blob_t* const* top, int ntop);
+void mms_layer_backward(mms_layer_t* l, mms_blob_t* const* top, int ntop,
+                        const int* propagate_down, mms_blob_t* const* bottom,
+                        int nbottom);
+int mms_layer_num_param_blobs(mms_layer_t* l);
+mms_blob_t* mms_layer_param_blob(mms_layer_t* l, int i); /* borrowed; do not destroy */
+void mms_layer_set_param_propagate_down(mms_layer_t* l, int i, int v);
+
+/* Caffe::set_mode (include/caffe/common.hpp): 0 = CPU, 1 = GPU (default).
+ * This library is GPU-only: Forward/Backward in CPU mode is a fatal error. */
+void mms_caffe_set_mode(int gpu);
+void mms_caffe_set_random_seed(unsigned seed);
+/* Comma-separated registered layer types ("PairRankLoss,SimCross,SimMatrix"). */
+const char* mms_layer_registry_types(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMS_LAYER_H_ */

@@ -1,0 +1,614 @@
+// csrc/caffe_layers.cpp -- SimCross / SimMatrix / PairRankLoss as Caffe layers
+// whose Forward_gpu / Backward_gpu are the HIP kernels behind include/mms.h,
+// plus fillers, the prototxt-subset reader and the C handle API of
+// include/mms_layer.h.  Builds into libmms_caffe.so (links libmms_hip.so).
+//
+// Layer set-up, shape rules, parameter blob order and every reference-visible
+// quirk follow the reference sources cited next to each method; the compute
+// bodies are not restated here at all -- they are calls into the C ABI.
+// CPU mode is deliberately absent: this library is the GPU implementation,
+// and a silent host fallback would void every parity claim.
+#include "caffe_api.hpp"
+
+#include <cctype>
+
+#include "mms.h"
+#include "mms_layer.h"
+
+namespace caffe {
+
+// --------------------------------- RNG + fillers -----------------------------
+std::mt19937& caffe_rng() {
+  static std::mt19937 g(std::random_device{}());
+  return g;
+}
+void caffe_set_random_seed(unsigned seed) { caffe_rng().seed(seed); }
+
+template <typename Dtype>
+class ConstantFiller : public Filler<Dtype> {
+ public:
+  using Filler<Dtype>::Filler;
+  void Fill(Blob<Dtype>* blob) override {
+    Dtype* data = blob->mutable_cpu_data();
+    const Dtype v = this->filler_param_.value();
+    for (int i = 0; i < blob->count(); ++i) data[i] = v;
+  }
+};
+template <typename Dtype>
+class UniformFiller : public Filler<Dtype> {
+ public:
+  using Filler<Dtype>::Filler;
+  void Fill(Blob<Dtype>* blob) override {
+    CHECK(blob->count());
+    std::uniform_real_distribution<Dtype> d(this->filler_param_.min(), this->filler_param_.max());
+    Dtype* data = blob->mutable_cpu_data();
+    for (int i = 0; i < blob->count(); ++i) data[i] = d(caffe_rng());
+  }
+};
+template <typename Dtype>
+class GaussianFiller : public Filler<Dtype> {
+ public:
+  using Filler<Dtype>::Filler;
+  void Fill(Blob<Dtype>* blob) override {
+    CHECK(blob->count());
+    std::normal_distribution<Dtype> d(this->filler_param_.mean(), this->filler_param_.std());
+    Dtype* data = blob->mutable_cpu_data();
+    for (int i = 0; i < blob->count(); ++i) data[i] = d(caffe_rng());
+  }
+};
+template <typename Dtype>
+class XavierFiller : public Filler<Dtype> {  // fan-in variance norm
+ public:
+  using Filler<Dtype>::Filler;
+  void Fill(Blob<Dtype>* blob) override {
+    CHECK(blob->count());
+    const int fan_in = blob->count() / blob->num();
+    const Dtype scale = std::sqrt(Dtype(3) / fan_in);
+    std::uniform_real_distribution<Dtype> d(-scale, scale);
+    Dtype* data = blob->mutable_cpu_data();
+    for (int i = 0; i < blob->count(); ++i) data[i] = d(caffe_rng());
+  }
+};
+template <typename Dtype>
+Filler<Dtype>* GetFiller(const FillerParameter& param) {
+  const string& type = param.type();
+  if (type == "constant") return new ConstantFiller<Dtype>(param);
+  if (type == "uniform") return new UniformFiller<Dtype>(param);
+  if (type == "gaussian") return new GaussianFiller<Dtype>(param);
+  if (type == "xavier") return new XavierFiller<Dtype>(param);
+  CHECK(false) << "Unknown filler name: " << type;
+  return nullptr;
+}
+template Filler<float>* GetFiller<float>(const FillerParameter&);
+
+static void mms_check(int rc, const char* what) {
+  CHECK_EQ(rc, (int)MMS_OK) << what << ": " << mms_error_string(rc);
+}
+#define NO_CPU_MODE MMS_FATAL("") << this->type() << " Layer: libmms is the GPU (HIP) implementation; " \
+  "CPU mode is served by the reference's own Forward_cpu/Backward_cpu, not by this library."
+
+// ===================================== SimCross ==============================
+// Reference: include/caffe/layers/sim_cross_layer.hpp, src/caffe/layers/sim_cross_layer.cpp
+template <typename Dtype>
+class SimCrossLayer : public Layer<Dtype> {
+ public:
+  explicit SimCrossLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  const char* type() const override { return "SimCross"; }
+  int ExactNumBottomBlobs() const override { return 2; }
+  int ExactNumTopBlobs() const override { return 1; }
+
+  // sim_cross_layer.cpp:10-47.  Quirks kept: pre-loaded blobs_ are NOT honoured
+  // (no "Skipping parameter initialization" branch) and param_propagate_down_
+  // is never sized.
+  void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    CHECK(bottom.size() == 2);
+    CHECK(bottom[0]->num() == bottom[1]->num());
+    CHECK(bottom[0]->height() == bottom[1]->height());
+    const SimCrossParameter& p = this->layer_param_.sim_cross_param();
+    dist_mode_ = p.dist_mode();
+    CHECK(dist_mode_ >= 0 && dist_mode_ <= 2) << "dist_mode must be 0 (cosine), 1 (euclid) or 2 (bilinear)";
+    if (dist_mode_ == 2) {
+      const bool bias_term = p.bias_term();
+      this->blobs_.resize(bias_term ? 2 : 1);
+      this->blobs_[0].reset(new Blob<Dtype>(vector<int>{p.mesure_count(), bottom[0]->height(), bottom[1]->height()}));
+      shared_ptr<Filler<Dtype> > wf(GetFiller<Dtype>(p.weight_filler()));
+      wf->Fill(this->blobs_[0].get());
+      if (bias_term) {
+        this->blobs_[1].reset(new Blob<Dtype>(vector<int>{p.mesure_count(), bottom[0]->channels(), bottom[1]->channels()}));
+        shared_ptr<Filler<Dtype> > bf(GetFiller<Dtype>(p.bias_filler()));
+        bf->Fill(this->blobs_[1].get());
+      }
+    }
+  }
+
+  // sim_cross_layer.cpp:50-80.  top = (N, M|1, W1, W2); data{0,1}_norm_ for mode 0.
+  void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    const int M = dist_mode_ == 2 ? this->layer_param_.sim_cross_param().mesure_count() : 1;
+    top[0]->Reshape(vector<int>{bottom[0]->num(), M, bottom[0]->channels(), bottom[1]->channels()});
+    if (dist_mode_ == 0) {
+      data0_norm_.Reshape(vector<int>{bottom[0]->num(), bottom[0]->channels()});
+      data1_norm_.Reshape(vector<int>{bottom[1]->num(), bottom[1]->channels()});
+    }
+    const size_t ws = mms_simcross_workspace_bytes(dist_mode_, bottom[0]->num(), bottom[0]->channels(),
+                                                   bottom[1]->channels(), bottom[0]->height(), M);
+    if (ws) workspace_.Reshape(vector<int>{(int)((ws + sizeof(Dtype) - 1) / sizeof(Dtype))});
+  }
+
+ protected:
+  void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
+  void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
+
+  // replaces sim_cross_layer.cpp:83-163 / sim_cross_layer.cu:128-194
+  void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    const int M = top[0]->channels();
+    const bool mode2 = dist_mode_ == 2, mode0 = dist_mode_ == 0;
+    mms_check(mms_simcross_forward_f32(
+                  dist_mode_, bottom[0]->num(), bottom[0]->channels(), bottom[1]->channels(),
+                  bottom[0]->height(), M, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
+                  mode2 ? this->blobs_[0]->gpu_data() : nullptr,
+                  (mode2 && this->blobs_.size() > 1) ? this->blobs_[1]->gpu_data() : nullptr,
+                  top[0]->mutable_gpu_data(), mode0 ? data0_norm_.mutable_gpu_data() : nullptr,
+                  mode0 ? data1_norm_.mutable_gpu_data() : nullptr,
+                  workspace_.count() ? workspace_.mutable_gpu_data() : nullptr,
+                  (size_t)workspace_.count() * sizeof(Dtype), nullptr),
+              "mms_simcross_forward_f32");
+  }
+
+  // replaces sim_cross_layer.cpp:166-307 / sim_cross_layer.cu:197-243
+  void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down,
+                    const vector<Blob<Dtype>*>& bottom) override {
+    const int M = top[0]->channels();
+    const bool mode2 = dist_mode_ == 2, mode0 = dist_mode_ == 0;
+    const bool bias_term = mode2 && this->blobs_.size() > 1;
+    mms_check(mms_simcross_backward_f32(
+                  dist_mode_, bottom[0]->num(), bottom[0]->channels(), bottom[1]->channels(),
+                  bottom[0]->height(), M, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
+                  mode2 ? this->blobs_[0]->gpu_data() : nullptr, bias_term, top[0]->gpu_data(),
+                  top[0]->gpu_diff(), mode0 ? data0_norm_.gpu_data() : nullptr,
+                  mode0 ? data1_norm_.gpu_data() : nullptr, propagate_down[0], propagate_down[1],
+                  bottom[0]->mutable_gpu_diff(), bottom[1]->mutable_gpu_diff(),
+                  mode2 ? this->blobs_[0]->mutable_gpu_diff() : nullptr,
+                  bias_term ? this->blobs_[1]->mutable_gpu_diff() : nullptr,
+                  workspace_.count() ? workspace_.mutable_gpu_data() : nullptr,
+                  (size_t)workspace_.count() * sizeof(Dtype), nullptr),
+              "mms_simcross_backward_f32");
+  }
+
+  int dist_mode_ = 1;  // 1 euclid, 0 cosine, 2 bilinear (sim_cross_layer.hpp:36)
+  Blob<Dtype> data0_norm_, data1_norm_;
+  Blob<Dtype> workspace_;  // replaces measure_temp{0,1}_
+};
+INSTANTIATE_CLASS(SimCrossLayer);
+REGISTER_LAYER_CLASS(SimCross);
+
+// ===================================== SimMatrix =============================
+// Reference: include/caffe/layers/sim_matrix_layer.hpp, src/caffe/layers/sim_matrix_layer.cpp
+template <typename Dtype>
+class SimMatrixLayer : public Layer<Dtype> {
+ public:
+  explicit SimMatrixLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  const char* type() const override { return "SimMatrix"; }
+  int ExactNumBottomBlobs() const override { return 2; }
+  int ExactNumTopBlobs() const override { return 1; }
+
+  // sim_matrix_layer.cpp:10-34 (honours pre-loaded blobs)
+  void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    CHECK_EQ(bottom[0]->num(), bottom[1]->num());
+    K1_ = bottom[0]->count(1);
+    K2_ = bottom[1]->count(1);
+    if (this->blobs_.size() > 0) {
+      LOG_INFO << "Skipping parameter initialization";
+    } else {
+      this->blobs_.resize(1);
+      this->blobs_[0].reset(new Blob<Dtype>(vector<int>{K1_, K2_}));
+      shared_ptr<Filler<Dtype> > wf(GetFiller<Dtype>(this->layer_param_.sim_matrix_param().weight_filler()));
+      wf->Fill(this->blobs_[0].get());
+    }
+    this->param_propagate_down_.resize(this->blobs_.size(), true);
+  }
+
+  // sim_matrix_layer.cpp:37-50
+  void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    CHECK_EQ(K1_, bottom[0]->count(1)) << "Input size incompatible with inner product parameters.";
+    CHECK_EQ(K2_, bottom[1]->count(1)) << "Input size incompatible with inner product parameters.";
+    M_ = bottom[0]->count(0, 1);
+    top[0]->Reshape(vector<int>{bottom[0]->shape(0), 1});
+    const size_t ws = mms_simmatrix_workspace_bytes(M_, K1_, K2_);
+    workspace_.Reshape(vector<int>{(int)((ws + sizeof(Dtype) - 1) / sizeof(Dtype))});
+  }
+
+ protected:
+  void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
+  void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
+
+  // replaces sim_matrix_layer.cpp:53-65; Q*W lands in bottom[1]'s diff, as in the reference (:58)
+  void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    mms_check(mms_simmatrix_forward_f32(M_, K1_, K2_, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
+                                        this->blobs_[0]->gpu_data(), top[0]->mutable_gpu_data(),
+                                        bottom[1]->mutable_gpu_diff(), nullptr),
+              "mms_simmatrix_forward_f32");
+  }
+  // replaces sim_matrix_layer.cpp:68-95
+  void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down,
+                    const vector<Blob<Dtype>*>& bottom) override {
+    const bool ppd = this->param_propagate_down_[0];
+    mms_check(mms_simmatrix_backward_f32(
+                  M_, K1_, K2_, bottom[0]->gpu_data(), bottom[1]->gpu_data(), this->blobs_[0]->gpu_data(),
+                  top[0]->gpu_diff(), ppd, propagate_down[0], propagate_down[1],
+                  propagate_down[0] ? bottom[0]->mutable_gpu_diff() : nullptr,
+                  propagate_down[1] ? bottom[1]->mutable_gpu_diff() : nullptr,
+                  ppd ? this->blobs_[0]->mutable_gpu_diff() : nullptr, workspace_.mutable_gpu_data(),
+                  (size_t)workspace_.count() * sizeof(Dtype), nullptr),
+              "mms_simmatrix_backward_f32");
+  }
+  int K1_ = 0, K2_ = 0, M_ = 0;
+  Blob<Dtype> workspace_;
+};
+INSTANTIATE_CLASS(SimMatrixLayer);
+REGISTER_LAYER_CLASS(SimMatrix);
+
+// ================================ LossLayer / PairRankLoss ===================
+// Reference: include/caffe/layers/loss_layer.hpp:22-49, src/caffe/layers/loss_layer.cpp:8-23
+template <typename Dtype>
+class LossLayer : public Layer<Dtype> {
+ public:
+  explicit LossLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    if (this->layer_param_.loss_weight_size() == 0) this->layer_param_.add_loss_weight(Dtype(1));
+  }
+  void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    CHECK_EQ(bottom[0]->num(), bottom[1]->num()) << "The data and label should have the same number.";
+    top[0]->Reshape(vector<int>());  // scalar, 0 axes
+  }
+  int ExactNumBottomBlobs() const override { return 2; }
+  bool AutoTopBlobs() const override { return true; }
+  int ExactNumTopBlobs() const override { return 1; }
+  bool AllowForceBackward(int bottom_index) const override { return bottom_index != 1; }
+};
+
+// Reference: include/caffe/layers/pair_rank_loss_layer.hpp, src/caffe/layers/pair_rank_loss_layer.cpp
+template <typename Dtype>
+class PairRankLossLayer : public LossLayer<Dtype> {
+ public:
+  explicit PairRankLossLayer(const LayerParameter& param) : LossLayer<Dtype>(param) {}
+  const char* type() const override { return "PairRankLoss"; }
+  int ExactNumBottomBlobs() const override { return 3; }
+  int ExactNumTopBlobs() const override { return -1; }
+  int MinTopBlobs() const override { return 1; }
+  int MaxTopBlobs() const override { return 2; }  // declared; only top[0] is ever written
+
+  // pair_rank_loss_layer.cpp:10-23.  The caches are shaped ONCE here (there is no
+  // Reshape override), so the batch must not grow after SetUp -- as in the reference.
+  void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    LossLayer<Dtype>::LayerSetUp(bottom, top);
+    CHECK_EQ(bottom[0]->num(), bottom[1]->num());
+    CHECK_EQ(bottom[0]->num(), bottom[2]->num());
+    CHECK_EQ(bottom[0]->count(1), bottom[2]->count(1));
+    CHECK_EQ(bottom[0]->count(1), bottom[1]->count(1));
+    margin_ = (Dtype)this->layer_param_.pair_rank_loss_param().margin();
+    ordered_diff_.Reshape(bottom[0]->num(), bottom[0]->channels(), 1, 1);
+    similar_diff_.Reshape(bottom[0]->num(), bottom[0]->channels(), 1, 1);
+    const size_t ws = mms_pairrank_workspace_bytes(ordered_diff_.count());
+    if (ws) workspace_.Reshape(vector<int>{(int)((ws + sizeof(Dtype) - 1) / sizeof(Dtype))});
+  }
+
+ protected:
+  void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
+  void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
+
+  // replaces pair_rank_loss_layer.cpp:26-52 / .cu:10-43
+  void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    const int count = bottom[0]->count();
+    CHECK_LE(count, ordered_diff_.count()) << "PairRankLoss caches are sized in LayerSetUp; batch grew";
+    mms_check(mms_pairrank_forward_f32(count, margin_, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
+                                       bottom[2]->gpu_data(), ordered_diff_.mutable_gpu_data(),
+                                       similar_diff_.mutable_gpu_data(), top[0]->mutable_gpu_data(),
+                                       workspace_.count() ? workspace_.mutable_gpu_data() : nullptr,
+                                       (size_t)workspace_.count() * sizeof(Dtype), nullptr),
+              "mms_pairrank_forward_f32");
+  }
+  // replaces pair_rank_loss_layer.cpp:55-84 (CPU semantics: strict '>')
+  void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down,
+                    const vector<Blob<Dtype>*>& bottom) override {
+    if (propagate_down[2]) LOG_FATAL << this->type() << " Layer cannot backpropagate to label inputs.";
+    if (!propagate_down[0] && !propagate_down[1]) return;
+    mms_check(mms_pairrank_backward_f32(bottom[0]->count(), top[0]->cpu_diff()[0], bottom[2]->gpu_data(),
+                                        ordered_diff_.gpu_data(), similar_diff_.gpu_data(),
+                                        propagate_down[0], propagate_down[1],
+                                        propagate_down[0] ? bottom[0]->mutable_gpu_diff() : nullptr,
+                                        propagate_down[1] ? bottom[1]->mutable_gpu_diff() : nullptr, nullptr),
+              "mms_pairrank_backward_f32");
+  }
+  Dtype margin_ = 1;
+  Blob<Dtype> ordered_diff_, similar_diff_, workspace_;
+};
+INSTANTIATE_CLASS(PairRankLossLayer);
+REGISTER_LAYER_CLASS(PairRankLoss);
+
+// ============================ prototxt (text format) subset ==================
+namespace {
+struct Tok {
+  enum Kind { END, IDENT, STRING, NUMBER, LBRACE, RBRACE, COLON } kind;
+  string text;
+};
+class Lexer {
+ public:
+  explicit Lexer(const string& s) : s_(s) {}
+  bool next(Tok* t, string* err) {
+    while (i_ < s_.size()) {
+      const char c = s_[i_];
+      if (std::isspace((unsigned char)c) || c == ',' || c == ';') { ++i_; continue; }
+      if (c == '#') { while (i_ < s_.size() && s_[i_] != '\n') ++i_; continue; }
+      break;
+    }
+    if (i_ >= s_.size()) { t->kind = Tok::END; return true; }
+    const char c = s_[i_];
+    if (c == '{' || c == '<') { ++i_; t->kind = Tok::LBRACE; return true; }
+    if (c == '}' || c == '>') { ++i_; t->kind = Tok::RBRACE; return true; }
+    if (c == ':') { ++i_; t->kind = Tok::COLON; return true; }
+    if (c == '"' || c == '\'') {
+      const char q = c;
+      size_t j = ++i_;
+      string out;
+      while (j < s_.size() && s_[j] != q) {
+        if (s_[j] == '\\' && j + 1 < s_.size()) ++j;
+        out += s_[j++];
+      }
+      if (j >= s_.size()) { *err = "unterminated string"; return false; }
+      i_ = j + 1;
+      t->kind = Tok::STRING; t->text = out;
+      return true;
+    }
+    if (std::isalpha((unsigned char)c) || c == '_') {
+      size_t j = i_;
+      while (j < s_.size() && (std::isalnum((unsigned char)s_[j]) || s_[j] == '_')) ++j;
+      t->kind = Tok::IDENT; t->text = s_.substr(i_, j - i_); i_ = j;
+      return true;
+    }
+    if (std::isdigit((unsigned char)c) || c == '-' || c == '+' || c == '.') {
+      size_t j = i_ + 1;
+      while (j < s_.size() && (std::isalnum((unsigned char)s_[j]) || s_[j] == '.' || s_[j] == '-' || s_[j] == '+')) ++j;
+      t->kind = Tok::NUMBER; t->text = s_.substr(i_, j - i_); i_ = j;
+      return true;
+    }
+    *err = string("unexpected character '") + c + "'";
+    return false;
+  }
+ private:
+  const string& s_;
+  size_t i_ = 0;
+};
+
+class Parser {
+ public:
+  explicit Parser(const string& s) : lex_(s) {}
+  bool fail(const string& m) { if (err_.empty()) err_ = m; return false; }
+  const string& err() const { return err_; }
+  bool advance() { return lex_.next(&cur_, &err_); }
+  Tok cur_;
+
+  // after a field name: scalar value
+  bool scalar(Tok* v) {
+    if (cur_.kind != Tok::COLON) return fail("expected ':'");
+    if (!advance()) return false;
+    if (cur_.kind != Tok::STRING && cur_.kind != Tok::NUMBER && cur_.kind != Tok::IDENT) return fail("expected a value");
+    *v = cur_;
+    return advance();
+  }
+  bool as_float(const Tok& t, float* f) {
+    char* end = nullptr;
+    *f = std::strtof(t.text.c_str(), &end);
+    if (t.kind != Tok::NUMBER || end == t.text.c_str()) return fail("expected a number, got '" + t.text + "'");
+    return true;
+  }
+  bool as_int(const Tok& t, int* i) {
+    char* end = nullptr;
+    const long v = std::strtol(t.text.c_str(), &end, 0);
+    if (t.kind != Tok::NUMBER || *end != '\0') return fail("expected an integer, got '" + t.text + "'");
+    *i = (int)v;
+    return true;
+  }
+  bool as_bool(const Tok& t, bool* b) {
+    if (t.text == "true" || t.text == "1") { *b = true; return true; }
+    if (t.text == "false" || t.text == "0") { *b = false; return true; }
+    return fail("expected a bool, got '" + t.text + "'");
+  }
+  // after a field name: `{ ... }` or `: { ... }`, body handled by f(field_name)
+  template <typename F>
+  bool message(F f) {
+    if (cur_.kind == Tok::COLON && !advance()) return false;
+    if (cur_.kind != Tok::LBRACE) return fail("expected '{'");
+    if (!advance()) return false;
+    while (cur_.kind == Tok::IDENT) {
+      const string name = cur_.text;
+      if (!advance()) return false;
+      if (!f(name)) return fail("unknown or malformed field '" + name + "'");
+    }
+    if (cur_.kind != Tok::RBRACE) return fail("expected '}'");
+    return advance();
+  }
+  bool skip_message() { return message([&](const string&) { return skip_value(); }); }
+  bool skip_value() {
+    if (cur_.kind == Tok::LBRACE) return skip_message();
+    if (cur_.kind != Tok::COLON) return fail("expected ':' or '{'");
+    if (!advance()) return false;
+    if (cur_.kind == Tok::LBRACE) return skip_message();
+    return advance();
+  }
+  bool filler(FillerParameter* fp) {
+    return message([&](const string& n) {
+      Tok v;
+      if (!scalar(&v)) return false;
+      if (n == "type") { fp->type_ = v.text; return true; }
+      if (n == "value") return as_float(v, &fp->value_);
+      if (n == "min") return as_float(v, &fp->min_);
+      if (n == "max") return as_float(v, &fp->max_);
+      if (n == "mean") return as_float(v, &fp->mean_);
+      if (n == "std") return as_float(v, &fp->std_);
+      if (n == "sparse" || n == "variance_norm") return true;
+      return false;
+    });
+  }
+  bool layer_field(const string& n, LayerParameter* lp) {
+    Tok v;
+    if (n == "name") { if (!scalar(&v)) return false; lp->name_ = v.text; return true; }
+    if (n == "type") { if (!scalar(&v)) return false; lp->type_ = v.text; return true; }
+    if (n == "bottom") { if (!scalar(&v)) return false; lp->bottom_.push_back(v.text); return true; }
+    if (n == "top") { if (!scalar(&v)) return false; lp->top_.push_back(v.text); return true; }
+    if (n == "loss_weight") { float f; if (!scalar(&v) || !as_float(v, &f)) return false; lp->loss_weight_.push_back(f); return true; }
+    if (n == "phase" || n == "propagate_down") { return scalar(&v); }
+    if (n == "include" || n == "exclude") return skip_value();
+    if (n == "param") {
+      ParamSpec ps;
+      if (!message([&](const string& m) {
+            Tok w;
+            if (!scalar(&w)) return false;
+            if (m == "name") { ps.name = w.text; return true; }
+            if (m == "lr_mult") return as_float(w, &ps.lr_mult);
+            if (m == "decay_mult") return as_float(w, &ps.decay_mult);
+            if (m == "share_mode") return true;
+            return false;
+          })) return false;
+      lp->param_.push_back(ps);
+      return true;
+    }
+    if (n == "sim_cross_param") {
+      SimCrossParameter* p = &lp->sim_cross_param_;
+      return message([&](const string& m) {
+        if (m == "weight_filler") return filler(&p->weight_filler_);
+        if (m == "bias_filler") return filler(&p->bias_filler_);
+        Tok w;
+        if (!scalar(&w)) return false;
+        if (m == "dist_mode") return as_int(w, &p->dist_mode_);
+        if (m == "mesure_count") return as_int(w, &p->mesure_count_);
+        if (m == "bias_term") return as_bool(w, &p->bias_term_);
+        return false;
+      });
+    }
+    if (n == "sim_matrix_param") {
+      return message([&](const string& m) {
+        if (m == "weight_filler") return filler(&lp->sim_matrix_param_.weight_filler_);
+        return false;
+      });
+    }
+    if (n == "pair_rank_loss_param") {
+      return message([&](const string& m) {
+        Tok w;
+        if (!scalar(&w)) return false;
+        if (m == "margin") return as_float(w, &lp->pair_rank_loss_param_.margin_);
+        return false;
+      });
+    }
+    return false;
+  }
+ private:
+  Lexer lex_;
+  string err_;
+};
+}  // namespace
+
+bool ReadLayerParameterFromText(const string& text, LayerParameter* out, string* err) {
+  Parser p(text);
+  *out = LayerParameter();
+  bool ok = p.advance();
+  if (ok && p.cur_.kind == Tok::IDENT && (p.cur_.text == "layer" || p.cur_.text == "layers")) {
+    ok = p.advance() && p.message([&](const string& n) { return p.layer_field(n, out); });
+  } else if (ok) {
+    while (ok && p.cur_.kind == Tok::IDENT) {
+      const string name = p.cur_.text;
+      ok = p.advance() && (p.layer_field(name, out) || p.fail("unknown or malformed field '" + name + "'"));
+    }
+  }
+  if (ok && p.cur_.kind != Tok::END) ok = p.fail("trailing input after the layer message");
+  if (ok && out->type_.empty()) ok = p.fail("layer has no type");
+  if (!ok && err) *err = p.err().empty() ? "parse error" : p.err();
+  return ok;
+}
+
+}  // namespace caffe
+
+// ================================== C handle API =============================
+struct mms_blob {
+  caffe::Blob<float>* b;
+  std::shared_ptr<caffe::Blob<float> > keep;  // set for borrowed parameter blobs
+  bool owned;
+};
+struct mms_layer {
+  std::shared_ptr<caffe::Layer<float> > l;
+  std::vector<std::unique_ptr<mms_blob> > param_handles;
+};
+
+namespace {
+std::vector<caffe::Blob<float>*> unwrap(mms_blob_t* const* v, int n) {
+  std::vector<caffe::Blob<float>*> out(n);
+  for (int i = 0; i < n; ++i) out[i] = v[i]->b;
+  return out;
+}
+std::vector<int> shape_vec(const int* shape, int n) { return std::vector<int>(shape, shape + n); }
+}  // namespace
+
+extern "C" {
+
+mms_blob_t* mms_blob_create(const int* shape, int num_axes) {
+  mms_blob_t* h = new mms_blob{new caffe::Blob<float>(shape_vec(shape, num_axes)), nullptr, true};
+  return h;
+}
+void mms_blob_destroy(mms_blob_t* b) {
+  if (!b) return;
+  if (b->owned) delete b->b;
+  delete b;
+}
+void mms_blob_reshape(mms_blob_t* b, const int* shape, int num_axes) { b->b->Reshape(shape_vec(shape, num_axes)); }
+int mms_blob_num_axes(const mms_blob_t* b) { return b->b->num_axes(); }
+int mms_blob_shape(const mms_blob_t* b, int axis) { return b->b->shape(axis); }
+int mms_blob_count(const mms_blob_t* b) { return b->b->count(); }
+const float* mms_blob_cpu(mms_blob_t* b, int which) { return which ? b->b->cpu_diff() : b->b->cpu_data(); }
+float* mms_blob_mutable_cpu(mms_blob_t* b, int which) { return which ? b->b->mutable_cpu_diff() : b->b->mutable_cpu_data(); }
+const float* mms_blob_gpu(mms_blob_t* b, int which) { return which ? b->b->gpu_diff() : b->b->gpu_data(); }
+float* mms_blob_mutable_gpu(mms_blob_t* b, int which) { return which ? b->b->mutable_gpu_diff() : b->b->mutable_gpu_data(); }
+
+mms_layer_t* mms_layer_create(const char* prototxt, char* err, int err_len) {
+  caffe::LayerParameter lp;
+  std::string e;
+  if (!caffe::ReadLayerParameterFromText(prototxt ? prototxt : "", &lp, &e)) {
+    if (err && err_len > 0) std::snprintf(err, err_len, "%s", e.c_str());
+    return nullptr;
+  }
+  mms_layer_t* h = new mms_layer;
+  h->l = caffe::LayerRegistry<float>::CreateLayer(lp);
+  return h;
+}
+void mms_layer_destroy(mms_layer_t* l) { delete l; }
+const char* mms_layer_type(const mms_layer_t* l) { return l->l->type(); }
+void mms_layer_setup(mms_layer_t* l, mms_blob_t* const* bottom, int nbottom, mms_blob_t* const* top, int ntop) {
+  l->l->SetUp(unwrap(bottom, nbottom), unwrap(top, ntop));
+}
+float mms_layer_forward(mms_layer_t* l, mms_blob_t* const* bottom, int nbottom, mms_blob_t* const* top, int ntop) {
+  return l->l->Forward(unwrap(bottom, nbottom), unwrap(top, ntop));
+}
+void mms_layer_backward(mms_layer_t* l, mms_blob_t* const* top, int ntop, const int* propagate_down,
+                        mms_blob_t* const* bottom, int nbottom) {
+  std::vector<bool> pd(nbottom);
+  for (int i = 0; i < nbottom; ++i) pd[i] = propagate_down[i] != 0;
+  l->l->Backward(unwrap(top, ntop), pd, unwrap(bottom, nbottom));
+}
+int mms_layer_num_param_blobs(mms_layer_t* l) { return (int)l->l->blobs().size(); }
+mms_blob_t* mms_layer_param_blob(mms_layer_t* l, int i) {
+  auto& blobs = l->l->blobs();
+  if (i < 0 || i >= (int)blobs.size()) return nullptr;
+  if ((int)l->param_handles.size() < (int)blobs.size()) l->param_handles.resize(blobs.size());
+  if (!l->param_handles[i] || l->param_handles[i]->b != blobs[i].get())
+    l->param_handles[i].reset(new mms_blob{blobs[i].get(), blobs[i], false});
+  return l->param_handles[i].get();
+}
+void mms_layer_set_param_propagate_down(mms_layer_t* l, int i, int v) { l->l->set_param_propagate_down(i, v != 0); }
+void mms_caffe_set_mode(int gpu) { caffe::Caffe::set_mode(gpu ? caffe::Caffe::GPU : caffe::Caffe::CPU); }
+void mms_caffe_set_random_seed(unsigned seed) { caffe::caffe_set_random_seed(seed); }
+const char* mms_layer_registry_types(void) {
+  static std::string s;
+  s.clear();
+  for (auto& t : caffe::LayerRegistry<float>::LayerTypeList()) s += (s.empty() ? "" : ",") + t;
+  return s.c_str();
+}
+
+}  // extern "C"

@@ -1,0 +1,228 @@
+"""Python face of the C++ Caffe-API mirror (libmms_caffe.so, include/mms_layer.h).
+
+Plays the role pycaffe plays for the reference (python/caffe/_caffe.cpp:212-340,
+python/caffe/net_spec.py:31-79): build a layer from its prototxt message or
+from NetSpec-style keyword arguments, wire Blobs, SetUp / Forward / Backward.
+
+    q, a, top = Blob((50, 40, 50)), Blob((50, 40, 50)), Blob()
+    sim = SimCross(dist_mode=2, mesure_count=4)            # like L.SimCross(q, a, ...)
+    sim.SetUp([q, a], [top]); sim.Forward([q, a], [top])
+
+All compute happens in the HIP library; this module only moves pointers.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmms_caffe.so")
+_lib = None
+
+_vp, _i, _ip, _fp = C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)
+_bpp = C.POINTER(C.c_void_p)
+
+_SIGNATURES = {
+    "mms_blob_create": (_vp, [_ip, _i]),
+    "mms_blob_destroy": (None, [_vp]),
+    "mms_blob_reshape": (None, [_vp, _ip, _i]),
+    "mms_blob_num_axes": (_i, [_vp]),
+    "mms_blob_shape": (_i, [_vp, _i]),
+    "mms_blob_count": (_i, [_vp]),
+    "mms_blob_cpu": (_fp, [_vp, _i]),
+    "mms_blob_mutable_cpu": (_fp, [_vp, _i]),
+    "mms_blob_gpu": (_vp, [_vp, _i]),
+    "mms_blob_mutable_gpu": (_vp, [_vp, _i]),
+    "mms_layer_create": (_vp, [C.c_char_p, C.c_char_p, _i]),
+    "mms_layer_destroy": (None, [_vp]),
+    "mms_layer_type": (C.c_char_p, [_vp]),
+    "mms_layer_setup": (None, [_vp, _bpp, _i, _bpp, _i]),
+    "mms_layer_forward": (C.c_float, [_vp, _bpp, _i, _bpp, _i]),
+    "mms_layer_backward": (None, [_vp, _bpp, _i, _ip, _bpp, _i]),
+    "mms_layer_num_param_blobs": (_i, [_vp]),
+    "mms_layer_param_blob": (_vp, [_vp, _i]),
+    "mms_layer_set_param_propagate_down": (None, [_vp, _i, _i]),
+    "mms_caffe_set_mode": (None, [_i]),
+    "mms_caffe_set_random_seed": (None, [C.c_uint]),
+    "mms_layer_registry_types": (C.c_char_p, []),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libmms_caffe.so is not built (%s); run __graft_entry__.build()" % LIB_PATH)
+        l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def registered_layer_types():
+    return lib().mms_layer_registry_types().decode().split(",")
+
+
+def set_mode_gpu():
+    lib().mms_caffe_set_mode(1)
+
+
+def set_mode_cpu():
+    lib().mms_caffe_set_mode(0)
+
+
+def set_random_seed(seed):
+    lib().mms_caffe_set_random_seed(int(seed))
+
+
+def _ints(seq):
+    seq = [int(x) for x in seq]
+    return (C.c_int * max(1, len(seq)))(*seq), len(seq)
+
+
+class Blob:
+    """caffe::Blob<float>.  `.data` / `.diff` are numpy views of the HOST side
+    (they move the SyncedMemory head to the CPU, like net.blobs[...].data)."""
+
+    def __init__(self, shape=(), _handle=None):
+        self._owned = _handle is None
+        if _handle is None:
+            arr, n = _ints(shape)
+            _handle = lib().mms_blob_create(arr, n)
+        self._h = _handle
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and self._h and _lib is not None:
+            _lib.mms_blob_destroy(self._h)
+            self._h = None
+
+    @property
+    def shape(self):
+        return tuple(lib().mms_blob_shape(self._h, i) for i in range(lib().mms_blob_num_axes(self._h)))
+
+    @property
+    def count(self):
+        return lib().mms_blob_count(self._h)
+
+    def reshape(self, *shape):
+        arr, n = _ints(shape)
+        lib().mms_blob_reshape(self._h, arr, n)
+
+    def _view(self, which, mutable):
+        f = lib().mms_blob_mutable_cpu if mutable else lib().mms_blob_cpu
+        p = f(self._h, which)
+        n = self.count
+        if n == 0:
+            return np.zeros(self.shape, np.float32)
+        return np.ctypeslib.as_array(p, shape=(n,)).reshape(self.shape)
+
+    @property
+    def data(self):
+        return self._view(0, True)
+
+    @property
+    def diff(self):
+        return self._view(1, True)
+
+    def gpu_data_ptr(self):
+        return lib().mms_blob_gpu(self._h, 0)
+
+    def gpu_diff_ptr(self):
+        return lib().mms_blob_gpu(self._h, 1)
+
+
+def _handles(blobs):
+    arr = (C.c_void_p * max(1, len(blobs)))(*[b._h for b in blobs])
+    return arr, len(blobs)
+
+
+def _text_value(v):
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, str):
+        return '"%s"' % v
+    return repr(v)
+
+
+def _text_message(d, indent=2):
+    """dict -> protobuf text format (the job of python/caffe/net_spec.py:56-79)."""
+    out = []
+    pad = " " * indent
+    for k, v in d.items():
+        for item in (v if isinstance(v, (list, tuple)) else [v]):
+            if isinstance(item, dict):
+                out.append("%s%s {\n%s%s}\n" % (pad, k, _text_message(item, indent + 2), pad))
+            else:
+                out.append("%s%s: %s\n" % (pad, k, _text_value(item)))
+    return "".join(out)
+
+
+class Layer:
+    """caffe::Layer<float> created through LayerRegistry::CreateLayer."""
+
+    def __init__(self, prototxt):
+        err = C.create_string_buffer(512)
+        self.prototxt = prototxt
+        self._h = lib().mms_layer_create(prototxt.encode(), err, 512)
+        if not self._h:
+            raise ValueError("prototxt: " + err.value.decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.mms_layer_destroy(self._h)
+            self._h = None
+
+    @property
+    def type(self):
+        return lib().mms_layer_type(self._h).decode()
+
+    def SetUp(self, bottom, top):
+        b, nb = _handles(bottom)
+        t, nt = _handles(top)
+        lib().mms_layer_setup(self._h, b, nb, t, nt)
+
+    def Forward(self, bottom, top):
+        b, nb = _handles(bottom)
+        t, nt = _handles(top)
+        return lib().mms_layer_forward(self._h, b, nb, t, nt)
+
+    def Backward(self, top, propagate_down, bottom):
+        b, nb = _handles(bottom)
+        t, nt = _handles(top)
+        pd, _ = _ints([1 if x else 0 for x in propagate_down])
+        lib().mms_layer_backward(self._h, t, nt, pd, b, nb)
+
+    @property
+    def blobs(self):
+        n = lib().mms_layer_num_param_blobs(self._h)
+        return [Blob(_handle=lib().mms_layer_param_blob(self._h, i)) for i in range(n)]
+
+    def set_param_propagate_down(self, i, v):
+        lib().mms_layer_set_param_propagate_down(self._h, int(i), 1 if v else 0)
+
+
+def _make(type_name, param_field, name=None, loss_weight=None, **kwargs):
+    d = {"name": name or type_name.lower(), "type": type_name}
+    if loss_weight is not None:
+        d["loss_weight"] = loss_weight
+    if kwargs:
+        d[param_field] = kwargs
+    return Layer("layer {\n%s}\n" % _text_message(d))
+
+
+def SimCross(**kw):
+    """L.SimCross(q, a, dist_mode=2, mesure_count=4, ...) -> sim_cross_param {...}
+    (do_trec_qa_clean.py:468; field names and defaults caffe.proto:471-477)."""
+    return _make("SimCross", "sim_cross_param", **kw)
+
+
+def SimMatrix(**kw):
+    return _make("SimMatrix", "sim_matrix_param", **kw)
+
+
+def PairRankLoss(**kw):
+    return _make("PairRankLoss", "pair_rank_loss_param", **kw)

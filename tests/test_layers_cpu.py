@@ -1,0 +1,72 @@
+"""CPU suite, part 3: the C++ Caffe-API mirror loads, registers the three layer
+types under the reference's type strings, and reads their prototxt messages with
+the reference's field names and defaults (no compute without a GPU)."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def L(hiplib):
+    from mms_answer_selection_amd import layers
+    layers.lib()
+    return layers
+
+
+def test_header_symbols_exported(L):
+    txt = open(os.path.join(ROOT, "include", "mms_layer.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = sorted(set(re.findall(r"\b(mms_[a-z0-9_]+)\s*\(", txt)))
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L.lib(), n), n
+    assert set(names) == set(L.EXPORTED_SYMBOLS)
+
+
+def test_registry_has_reference_type_strings(L):
+    # sim_cross_layer.hpp:22, sim_matrix_layer.hpp:22, pair_rank_loss_layer.hpp:24
+    assert sorted(L.registered_layer_types()) == ["PairRankLoss", "SimCross", "SimMatrix"]
+
+
+def test_prototxt_as_written_by_the_driver(L):
+    # what net_spec emits for L.SimCross(q, a, dist_mode=2, mesure_count=4, bias_term=True,
+    # param=[dict(name='embed-weights', decay_mult=1, lr_mult=1)])  (do_trec_qa_clean.py:468)
+    txt = '''
+    layer {
+      name: "sim_cross"
+      type: "SimCross"
+      bottom: "w2v_q"
+      bottom: "w2v_a"
+      top: "sim_cross"
+      param { name: "embed-weights" lr_mult: 1 decay_mult: 1 }
+      sim_cross_param {
+        dist_mode: 2
+        mesure_count: 4   # sic
+        bias_term: true
+      }
+    }'''
+    lay = L.Layer(txt)
+    assert lay.type == "SimCross"
+    assert L.Layer('type: "PairRankLoss" pair_rank_loss_param { margin: 0.1 } loss_weight: 2').type == "PairRankLoss"
+    assert L.Layer('layer { type: "SimMatrix" sim_matrix_param { weight_filler { type: "uniform" min: -0.08 max: 0.08 } } }').type == "SimMatrix"
+
+
+@pytest.mark.parametrize("bad", [
+    'layer { type: "SimCross" sim_cross_param { measure_count: 4 } }',   # correct spelling is NOT the field name
+    'layer { type: "SimCross" sim_cross_param { dist_mode: two } }',
+    'layer { type: "SimCross" sim_cross_param { dist_mode: 1 }',           # missing brace
+    'layer { name: "x" }',                                                  # no type
+    'layer { type: "SimCross" } trailing',
+])
+def test_prototxt_errors_are_reported(L, bad):
+    with pytest.raises(ValueError):
+        L.Layer(bad)
+
+
+def test_netspec_style_kwargs(L):
+    lay = L.SimCross(dist_mode=2, mesure_count=4, weight_filler=dict(type="uniform", min=-0.08, max=0.08))
+    assert 'mesure_count: 4' in lay.prototxt and 'type: "uniform"' in lay.prototxt
+    assert L.PairRankLoss(margin=0.5, loss_weight=1.0).type == "PairRankLoss"
