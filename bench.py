@@ -55,6 +55,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
+    p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                   help="nccl = RCCL over xGMI (default). gloo = rehearsal of the N>1 control flow "
+                        "on a box with fewer GPUs than ranks (scores staged through the host)")
     return p.parse_args()
 
 
@@ -137,10 +140,14 @@ def run(args):
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    local = local % torch.cuda.device_count() if args.backend == "gloo" else local
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     if rank == 0:
         build.build_all()
     if world > 1:
@@ -189,6 +196,20 @@ def run(args):
     else:
         period = 1
 
+    def gather_bucket(bi):
+        """All-gather of the per-pair scores of one bucket (GROUP steps x 4096 pairs per rank),
+        on the side stream, so it overlaps the next group's compute."""
+        comm.wait_stream(main)
+        with torch.cuda.stream(comm):
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered[bi].view(-1), buckets[bi].view(-1))
+            else:  # rehearsal: host-staged
+                h = buckets[bi].view(-1).cpu()
+                ho = torch.empty(world * h.numel())
+                dist.all_gather_into_tensor(ho, h)
+                gathered[bi].view(-1).copy_(ho)
+            bucket_free[bi].record(comm)
+
     def run_group(gi):
         if world > 1:
             main.wait_event(bucket_free[gi % 2])      # previous gather of this bucket done
@@ -197,10 +218,7 @@ def run(args):
         else:
             group_body(gi)
         if world > 1:
-            comm.wait_stream(main)
-            with torch.cuda.stream(comm):
-                dist.all_gather_into_tensor(gathered[gi % 2].view(-1), buckets[gi % 2].view(-1))
-                bucket_free[gi % 2].record(comm)
+            gather_bucket(gi % 2)
 
     def run_steps(k, g0):
         full, rem = divmod(k, G)
@@ -213,10 +231,7 @@ def run(args):
             for s in range(rem):
                 step(0 if args.warm else ((g0 + full) % ngroups) * G + s, b[s])
             if world > 1:
-                comm.wait_stream(main)
-                with torch.cuda.stream(comm):
-                    dist.all_gather_into_tensor(gathered[(g0 + full) % 2].view(-1), b.view(-1))
-                    bucket_free[(g0 + full) % 2].record(comm)
+                gather_bucket((g0 + full) % 2)
         return g0 + full + (1 if rem else 0)
 
     def fence():
@@ -248,9 +263,9 @@ def run(args):
         step_us_ev = ev_ms * 1e3 / args.steps            # HIP events on the launch stream
         achieved = B_UNFUSED / (step_us_ev * 1e-6) / 1e9 if args.path != "triplet" else None
         value = world * N_PAIRS * args.steps / wall
-        kernel = {"fused": "euclid_rows_kernel<BWD=true> (SimCross Euclid fwd+bwd, one launch)",
-                  "layers": "euclid_rows_kernel<BWD=false> + euclid_rows_bwd_kernel",
-                  "triplet": "triplet_euclid_kernel + loss_finish_kernel"}[args.path]
+        kernel = {"fused": "mms::euclid_rows_wave_kernel<3,true,true> (SimCross Euclid fwd+bwd, one launch)",
+                  "layers": "mms::euclid_rows_wave_kernel<3,true,false> + <3,false,true>",
+                  "triplet": "mms::triplet_wave_kernel<3> + loss_finish_kernel"}[args.path]
         out = {
             "metric": "QA pairs/sec (fwd+bwd) at batch 4096, 300-d; % HBM roofline",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,

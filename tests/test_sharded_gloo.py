@@ -1,0 +1,82 @@
+"""CPU suite, part 4: the N>1 path (pair sharding, score all-gather, dW
+all-reduce) with world_size 2 over gloo.  Per-rank inputs are computed with the
+oracle (as the checker's stand-in for the GPU kernels, which need a GPU); what
+is under test is that shard -> collective -> reassembly equals the unsharded
+result, including ragged shards."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from util import qa, rng
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mms_answer_selection_amd import sharded
+        from oracle import cpu_oracle as O
+        W1 = W2 = 3
+        D, M = 12, 2
+        r = rng(9)
+        q, a = qa(r, n, W1, W2, D)
+        Wt = r.uniform(-0.5, 0.5, (M, D, D)).astype(np.float32)
+        dT = r.standard_normal((n, M, W1, W2)).astype(np.float32)
+        lo, hi = sharded.shard_range(n, rank, world)
+        # forward on the shard, all-gather of scores
+        top_loc, _, _ = O.simcross_forward(2, q[lo:hi], a[lo:hi], Wt, None)
+        full = sharded.all_gather_scores(torch.from_numpy(top_loc), n)
+        top_ref, _, _ = O.simcross_forward(2, q, a, Wt, None)
+        ok_fwd = np.array_equal(full.numpy(), top_ref)
+        # backward on the shard: dq/da stay local, dW all-reduced
+        dq, da, dW, _ = O.simcross_backward(2, q[lo:hi], a[lo:hi], top_loc, dT[lo:hi], W=Wt)
+        dWt = torch.from_numpy(dW.copy())
+        extra = torch.full((3,), float(rank + 1))
+        sharded.all_reduce_param_grads([dWt, extra])
+        dq_ref, da_ref, dW_ref, _ = O.simcross_backward(2, q, a, top_ref, dT, W=Wt)
+        ok_local = np.array_equal(dq, dq_ref[lo:hi]) and np.array_equal(da, da_ref[lo:hi])
+        ok_dw = np.allclose(dWt.numpy(), dW_ref, rtol=1e-5, atol=1e-5) and float(extra[0]) == sum(range(1, world + 1))
+        # loss: per-rank sums -> global mean
+        sa = torch.from_numpy(top_loc[:, 0, 0, 0].copy())
+        mean = sharded.all_reduce_loss(sa.sum().reshape(1), n)
+        ok_loss = abs(float(mean) - float(top_ref[:, 0, 0, 0].sum()) / n) < 1e-5
+        ret[rank] = (ok_fwd, ok_local, ok_dw, ok_loss)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [8, 7, 1])     # even, ragged, fewer pairs than ranks
+def test_world2_gloo(n, oracle):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rk in range(world):
+        assert all(ret[rk]), (rk, ret[rk])
+
+
+def test_shard_bounds_cover_and_order():
+    from mms_answer_selection_amd import sharded
+    for n in (0, 1, 7, 4096, 1517):
+        for w in (1, 2, 3, 8):
+            b = sharded.shard_bounds(n, w)
+            assert b[0] == 0 and b[-1] == n and all(b[i] <= b[i + 1] for i in range(w))
+            assert max(b[i + 1] - b[i] for i in range(w)) - min(b[i + 1] - b[i] for i in range(w)) <= 1
