@@ -69,15 +69,16 @@ __device__ __forceinline__ float euclid_tt(const EuclidCoef& k, float diff) {
   return res;
 }
 
-// sum_d sq[d], d ascending, fp32, adds only -- the reference's accumulation
-// order for `dist += diff*diff` (sim_cross_layer.cpp:100-105) once the
-// squares are formed.  `r4` points at D4 float4 of squares in LDS.  The LDS
-// reads run one 8 x 16 B batch ahead of the adds, and the wave is prioritised
-// while it is latency-bound on this dependent chain.
-__device__ __forceinline__ float chain_sum_lds(const float4* r4, int D4) {
-  __builtin_amdgcn_s_setprio(3);
-  float dist = 0.f;
-  const int nb = D4 >> 3;
+// s = init; for i in [0, n4): s += r4[i].x, .y, .z, .w  (fp32, adds only, in
+// that order) -- the reference's accumulation order for `dist += diff*diff`
+// (sim_cross_layer.cpp:100-105) once the squares are formed.  `r4` points at
+// float4 squares in LDS.  The chain is bound by VALU issue (~4.5 cycles per
+// wave-instruction whatever the number of active lanes) as much as by add
+// latency, so the loop carries NOTHING but the adds: LDS reads run one
+// 8 x 16 B batch ahead with immediate offsets, and no per-element predicate.
+__device__ __forceinline__ float chain_sum_lds(const float4* r4, int n4, float init) {
+  float s = init;
+  const int nb = n4 >> 3;
   float4 va[8], vb[8];
   if (nb > 0) {
 #pragma unroll
@@ -89,7 +90,7 @@ __device__ __forceinline__ float chain_sum_lds(const float4* r4, int D4) {
     for (int u = 0; u < 8; ++u) vb[u] = r4[(b + 1) * 8 + u];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      dist += va[u].x; dist += va[u].y; dist += va[u].z; dist += va[u].w;
+      s += va[u].x; s += va[u].y; s += va[u].z; s += va[u].w;
     }
     if (b + 2 < nb) {
 #pragma unroll
@@ -97,21 +98,76 @@ __device__ __forceinline__ float chain_sum_lds(const float4* r4, int D4) {
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      dist += vb[u].x; dist += vb[u].y; dist += vb[u].z; dist += vb[u].w;
+      s += vb[u].x; s += vb[u].y; s += vb[u].z; s += vb[u].w;
     }
   }
   if (b < nb) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      dist += va[u].x; dist += va[u].y; dist += va[u].z; dist += va[u].w;
+      s += va[u].x; s += va[u].y; s += va[u].z; s += va[u].w;
     }
   }
-  for (int d = nb * 8; d < D4; ++d) {
+  for (int d = nb * 8; d < n4; ++d) {
     const float4 v = r4[d];
-    dist += v.x; dist += v.y; dist += v.z; dist += v.w;
+    s += v.x; s += v.y; s += v.z; s += v.w;
   }
+  return s;
+}
+
+// ---------------------------------------------------------------------------
+// Speculative two-segment evaluation of the d-ascending chain, bit-exact.
+//
+// A dependent fp32 add costs ~6.6 cycles of latency and ~4.5 issue cycles of
+// its SIMD no matter how few lanes are active (profiles/r01_chainbench_*), so
+// a D-long chain per pair is the critical path of the forward pass.  The chain
+// cannot be re-associated (it must round like the reference), but its second
+// half can be started before the first half has finished if the value the
+// first half will end on is GUESSED: the sequential fp32 partial sum differs
+// from a tree sum of the same terms by a few ulps only (random-walk rounding
+// error, sigma ~ 0.22*sqrt(n) ulp; 2.3 ulp at n = 150).  So each pair gets
+// LPR = 64/RW lanes:
+//   lane j = 0        walks segment 0 from 0           (exact prefix),
+//   lane j = 1..LPR-1 walks segment 1 from pred + (j - LPR/2) ulps,
+// where pred is a tree sum of segment 0.  When lane 0 finishes, its end value
+// s1 selects the candidate lane whose start value IS s1 -- that lane has
+// computed exactly the reference's continuation.  If s1 fell outside the
+// window (never observed at +-15 ulps for D = 300: > 6 sigma) the segment is
+// simply re-walked from s1.  The result is the reference's sum bit for bit in
+// every case; only the time varies.
+//
+// LDS layout of one pair ("split image", spec_lds_index below): segment 0
+// = squares [0, b4) padded with all-zero float4 up to h4 = D4 - b4 entries,
+// then segment 1 = squares [b4, D4) (h4 entries).  Adding +0 to the
+// non-negative running sum is exact, so both kinds of lane run the same h4
+// steps with no predicate in the loop.
+__device__ __forceinline__ int spec_b4(int D4) { return D4 >> 1; }
+__device__ __forceinline__ int spec_h4(int D4) { return D4 - (D4 >> 1); }
+__device__ __forceinline__ int spec_stride4(int D4) { return 2 * spec_h4(D4); }
+// position of square-float4 `i` (0 <= i < D4) inside the pair's split image
+__device__ __forceinline__ int spec_lds_index(int i, int D4) {
+  return i < spec_b4(D4) ? i : i + (spec_h4(D4) - spec_b4(D4));
+}
+
+// `img4`   this pair's split image in LDS (spec_stride4(D4) float4; the pad
+//          entries must already be zero)
+// `pred`   tree sum of segment 0 (any summation order; it only centres the window)
+// `j`      this lane's index within the pair's lane group; `lead` = lane id of j = 0
+// returns  the full sum, valid in EVERY lane of the group.
+template <int LPR>
+__device__ __forceinline__ float chain_sum_speculative(const float4* img4, int D4, float pred,
+                                                       int j, int lead) {
+  const int h4 = spec_h4(D4);
+  const bool exact_lane = (j == 0);
+  const float start = exact_lane ? 0.0f : __int_as_float(__float_as_int(pred) + (j - LPR / 2));
+  __builtin_amdgcn_s_setprio(3);
+  const float end = chain_sum_lds(img4 + (exact_lane ? 0 : h4), h4, start);
+  const float s1 = __shfl(end, lead, 64);                       // exact prefix sum
+  const int k = __float_as_int(s1) - __float_as_int(pred) + LPR / 2;   // candidate lane index
+  const bool hit = (k >= 1) && (k <= LPR - 1);
+  float total = __shfl(end, lead + (hit ? k : 0), 64);
+  if (!hit) total = chain_sum_lds(img4 + h4, h4, s1);           // re-walk, exact
   __builtin_amdgcn_s_setprio(0);
-  return dist;
+  return total;
 }
 
 // Compiler-level ordering between LDS writes of some lanes and LDS reads of

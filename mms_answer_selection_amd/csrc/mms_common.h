@@ -19,12 +19,25 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
-// Sum across the 64 lanes of a wave in a fixed butterfly order (deterministic).
-// Every lane ends with the total.
+// Sum across the 64 lanes of a wave in a fixed order (deterministic); every
+// lane ends with the total.  DPP cross-lane adds, no LDS round trips: xor-1 and
+// xor-2 inside quads, half-mirror and mirror inside each row of 16, then
+// row_bcast:15 / row_bcast:31 accumulate the four row totals into row 3, whose
+// lane 63 is broadcast.  (__shfl_xor lowers to ds_bpermute: ~100 cycles of LDS
+// latency per step, six dependent steps.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __int_as_float(moved);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-  return v;
+  v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);   // row_mirror      -> every lane holds its row's total
+  v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> row 3 holds the wave total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Sum across a workgroup of THREADS (multiple of 64) threads; result valid in

@@ -133,46 +133,40 @@ int pairrank_backward(int count, float top_diff, const float* y, const float* or
 // ======================= fused (q, a+, a-) training step =====================
 // Euclidean SimCross on (q,a+) and (q,a-), PairRankLoss on the two score
 // columns, and the whole backward, in one launch (+ a one-block loss finish).
-// Same wave-centric structure as euclid_rows_wave_kernel: a wave owns kTW = 2
-// triplets, issues all its 16-byte loads of q, a+, a- up front, keeps q-a+ and
-// q-a- in registers, and four lanes (2 triplets x 2 branches) walk the squares
-// d-ascending (reference order, sim_cross_layer.cpp:100-106).  Each input is
-// read once and each gradient written once.
-constexpr int kTW = 2;
-
-template <int NIT>
+// Same wave-centric structure as euclid_rows_wave_kernel: a wave owns ONE
+// triplet, issues all its 16-byte loads of q, a+, a- up front, keeps q-a+ and
+// q-a- in registers; lanes 0-31 evaluate the positive branch's d-ascending sum
+// and lanes 32-63 the negative branch's (speculative two-segment scheme of
+// euclid_math.h when SPEC, plain walk by lanes 0 / 32 otherwise; both are the
+// reference order, sim_cross_layer.cpp:100-106).  Each input is read once and
+// each gradient written once.
+template <int NIT, bool SPEC>
 __global__ __launch_bounds__(256) void triplet_wave_kernel(
     int N, int D4, float margin, float s0, float s1, const float* __restrict__ q,
     const float* __restrict__ ap, const float* __restrict__ an, const float* __restrict__ y,
     float* __restrict__ s_pos, float* __restrict__ s_neg, float* __restrict__ partials,
     float* __restrict__ dq, float* __restrict__ dap, float* __restrict__ dan) {
-  extern __shared__ float4 lds4[];               // [4 waves][2 branches][kTW * D4] squares
-  __shared__ float Ts[4][2][kTW];
-  __shared__ float cs[4][2][kTW];
-  __shared__ double dens[4][2][kTW];
-  __shared__ double rcps[4][2][kTW];
-  __shared__ float terms[4][kTW];
-
+  extern __shared__ float4 lds4[];               // [4 waves][2 branches] split images (euclid_math.h)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int gw = blockIdx.x * 4 + wave;
-  const int row0 = gw * kTW;
-  if (row0 >= N) return;
-  const int rows = min(kTW, N - row0);
-  const int n4 = rows * D4;
-  const size_t base4 = (size_t)row0 * D4;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= N) return;
+  const size_t base4 = (size_t)row * D4;
   const float4* q4 = reinterpret_cast<const float4*>(q) + base4;
   const float4* p4 = reinterpret_cast<const float4*>(ap) + base4;
   const float4* m4 = reinterpret_cast<const float4*>(an) + base4;
-  float4* sqp = lds4 + (size_t)wave * 2 * kTW * D4;
-  float4* sqn = sqp + kTW * D4;
+  const int st4 = spec_stride4(D4);
+  float4* sqp = lds4 + (size_t)wave * 2 * st4;
+  float4* sqn = sqp + st4;
 
   float4 x[NIT], u[NIT], v[NIT], dp[NIT], dn[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = lane + 64 * it;
-    const int ii = i < n4 ? i : 0;
+    const int ii = i < D4 ? i : 0;
     x[it] = q4[ii]; u[it] = p4[ii]; v[it] = m4[ii];
   }
+  const float yy = y[row];
+  float predp = 0.f, predn = 0.f;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = lane + 64 * it;
@@ -185,44 +179,38 @@ __global__ __launch_bounds__(256) void triplet_wave_kernel(
     a.z = dp[it].z * dp[it].z; a.w = dp[it].w * dp[it].w;
     b.x = dn[it].x * dn[it].x; b.y = dn[it].y * dn[it].y;
     b.z = dn[it].z * dn[it].z; b.w = dn[it].w * dn[it].w;
-    if (i < n4) { sqp[i] = a; sqn[i] = b; }
+    if (i < D4) { const int li = spec_lds_index(i, D4); sqp[li] = a; sqn[li] = b; }
+    const bool seg0 = i < spec_b4(D4);
+    predp += seg0 ? (a.x + a.y) + (a.z + a.w) : 0.f;
+    predn += seg0 ? (b.x + b.y) + (b.z + b.w) : 0.f;
   }
-  wave_lds_sync();
-
-  // lanes [0,kTW): positive branch of triplet `lane`; lanes [kTW,2kTW): negative.
-  if (lane < 2 * kTW) {
-    const int br = lane / kTW, r = lane % kTW;
-    if (r < rows) {
-      const float dist = chain_sum_lds((br ? sqn : sqp) + r * D4, D4);
-      const float T = 1.0f / (1.0f + sqrtf(dist));
-      Ts[wave][br][r] = T;
-      (br ? s_neg : s_pos)[row0 + r] = T;
+  if (lane < 2 && spec_h4(D4) > spec_b4(D4))
+    sqp[lane * st4 + spec_b4(D4)] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int br = lane >> 5, j = lane & 31;       // branch handled by this half-wave
+  float dist;
+  if (SPEC) {
+    predp = wave_sum(predp);
+    predn = wave_sum(predn);
+    wave_lds_sync();
+    dist = chain_sum_speculative<32>(br ? sqn : sqp, D4, br ? predn : predp, j, br * 32);
+  } else {
+    wave_lds_sync();
+    dist = 0.f;
+    if (j == 0) {   // plain walk over both halves of the split image (the pad adds +0: exact)
+      dist = chain_sum_lds(br ? sqn : sqp, st4, 0.f);
     }
+    dist = __shfl(dist, br * 32, 64);
   }
-  wave_lds_sync();
+  const float Tmine = 1.0f / (1.0f + sqrtf(dist));
+  const float Tp = __shfl(Tmine, 0, 64), Tn = __shfl(Tmine, 32, 64);
+  if (lane == 0) { s_pos[row] = Tp; s_neg[row] = Tn; }
 
-  if (lane < kTW) {
-    float t = 0.f;
-    if (lane < rows) {
-      const float yy = y[row0 + lane];
-      const float Tp = Ts[wave][0][lane], Tn = Ts[wave][1][lane];
-      const PairTerm p = pair_term(Tp, Tn, yy, margin);
-      float ga, gb;
-      pair_grad(yy, p.ordered, p.similar, s0, s1, ga, gb);
-      const EuclidCoef k0 = euclid_coef(Tp, ga), k1 = euclid_coef(Tn, gb);
-      cs[wave][0][lane] = k0.c; dens[wave][0][lane] = k0.den; rcps[wave][0][lane] = k0.rcp;
-      cs[wave][1][lane] = k1.c; dens[wave][1][lane] = k1.den; rcps[wave][1][lane] = k1.rcp;
-      t = p.term;
-    }
-    terms[wave][lane] = t;
-  }
-  wave_lds_sync();
-  if (lane == 0) {
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < kTW; ++r) s += terms[wave][r];
-    partials[gw] = s;
-  }
+  // PairRankLoss on (Tp, Tn, y): every lane computes the same scalars
+  const PairTerm pt = pair_term(Tp, Tn, yy, margin);
+  float ga, gb;
+  pair_grad(yy, pt.ordered, pt.similar, s0, s1, ga, gb);
+  if (lane == 0) partials[row] = pt.term;
+  const EuclidCoef k0 = euclid_coef(Tp, ga), k1 = euclid_coef(Tn, gb);
 
   // Layer-by-layer semantics: each SimCross backward produces dq_branch = 0 + tt and
   // da = 0 + (-tt); Caffe's Split layer then adds the two dq_branch blobs.
@@ -232,11 +220,7 @@ __global__ __launch_bounds__(256) void triplet_wave_kernel(
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = lane + 64 * it;
-    if (i >= n4) break;
-    const int r = i >= D4 ? 1 : 0;
-    EuclidCoef k0, k1;
-    k0.c = cs[wave][0][r]; k0.den = dens[wave][0][r]; k0.rcp = rcps[wave][0][r];
-    k1.c = cs[wave][1][r]; k1.den = dens[wave][1][r]; k1.rcp = rcps[wave][1][r];
+    if (i >= D4) break;
     float tp[4], tn[4];
     tp[0] = euclid_tt(k0, dp[it].x); tp[1] = euclid_tt(k0, dp[it].y);
     tp[2] = euclid_tt(k0, dp[it].z); tp[3] = euclid_tt(k0, dp[it].w);
@@ -326,10 +310,8 @@ __global__ __launch_bounds__(THREADS) void triplet_generic_kernel(
 constexpr int kTripRows = 8;
 constexpr int kTripThreads = 256;
 
-// one float per wave-pair of triplets (wave kernel) -- the generic kernel needs fewer
-size_t triplet_workspace_bytes(int N) {
-  return (size_t)((N + kTW - 1) / kTW) * sizeof(float);
-}
+// one float per triplet (wave kernel) -- the generic kernel needs fewer
+size_t triplet_workspace_bytes(int N) { return (size_t)N * sizeof(float); }
 
 int triplet_euclid_step(int N, int D, float margin, float loss_weight, const float* q,
                         const float* ap, const float* an, const float* y, float* s_pos,
@@ -342,23 +324,25 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
   float* partials = static_cast<float*>(ws);
   const bool v = (D % 4 == 0) && aligned16(q) && aligned16(ap) && aligned16(an) &&
                  aligned16(dq) && aligned16(dap) && aligned16(dan);
-  const int nit = (kTW * (D / 4) + 63) / 64;
   int nparts;
-  if (v && nit <= 8) {
+  if (v && D <= 1024) {
     const int D4 = D / 4;
-    nparts = (N + kTW - 1) / kTW;
-    const unsigned grid = (unsigned)((nparts + 3) / 4);
-    const size_t lds = (size_t)4 * 2 * kTW * D4 * sizeof(float4);
-    switch (nit) {
-#define MMS_NIT_CASE(n)                                                                        \
-  case n:                                                                                      \
-    hipLaunchKernelGGL((triplet_wave_kernel<n>), dim3(grid), dim3(256), lds, s, N, D4, margin, \
-                       s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan);            \
+    const int nit = (D4 + 63) / 64;
+    nparts = N;
+    const unsigned grid = (unsigned)((N + 3) / 4);
+    const size_t lds = (size_t)4 * 2 * 2 * (D4 - D4 / 2) * sizeof(float4);
+    const bool spec = D <= 400;   // +-15 ulp window: see euclid_math.h
+#define MMS_NIT_CASE(n)                                                                         \
+  case n:                                                                                       \
+    if (spec)                                                                                   \
+      hipLaunchKernelGGL((triplet_wave_kernel<n, true>), dim3(grid), dim3(256), lds, s, N, D4,  \
+                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan);   \
+    else                                                                                        \
+      hipLaunchKernelGGL((triplet_wave_kernel<n, false>), dim3(grid), dim3(256), lds, s, N, D4, \
+                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan);   \
     break;
-      MMS_NIT_CASE(1) MMS_NIT_CASE(2) MMS_NIT_CASE(3) MMS_NIT_CASE(4)
-      MMS_NIT_CASE(5) MMS_NIT_CASE(6) MMS_NIT_CASE(7) MMS_NIT_CASE(8)
+    switch (nit) { MMS_NIT_CASE(1) MMS_NIT_CASE(2) MMS_NIT_CASE(3) MMS_NIT_CASE(4) }
 #undef MMS_NIT_CASE
-    }
   } else {
     const size_t lds = 2 * (size_t)kTripRows * D * sizeof(float);
     if (lds > 96 * 1024) return MMS_ERR_UNSUPPORTED;

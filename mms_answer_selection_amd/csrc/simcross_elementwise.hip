@@ -29,40 +29,38 @@ namespace mms {
 // =============================== rows geometry ==============================
 
 // ---- wave-centric kernel (the fast path) ------------------------------------
-// A wave owns RW = 2 consecutive pairs (RW*D/4 float4 per operand); the four
-// waves of a workgroup are independent (no workgroup barrier).  Timeline of
-// one wave:
+// A wave owns RW (1 or 2) consecutive pairs (RW*D/4 float4 per operand); the
+// four waves of a workgroup are independent (no workgroup barrier).  Timeline
+// of one wave:
 //   1. ALL its 16-byte loads of q and a are issued back to back (NIT per
 //      operand per lane, predicated) -- nothing waits inside a loop;
 //   2. diff = q-a stays in registers; diff^2 goes to the wave's LDS slice;
-//   3. lanes 0..RW-1 each walk one pair's squares d-ascending with adds only
-//      (LDS reads batched 8 x 16 B ahead): the reference's summation order;
-//   4. those lanes publish T and the backward coefficients through LDS;
+//   3. the d-ascending sum of each pair's squares -- the reference's summation
+//      order -- is evaluated by the pair's 64/RW lanes with the speculative
+//      two-segment scheme of euclid_math.h (bit-exact, half the chain length);
+//   4. every lane derives T and the backward coefficients of its pair
+//      (wave-uniform per lane group; no LDS round trip);
 //   5. every lane turns its register-resident diffs into dq / da and stores
 //      16 bytes per lane.
 // FWD only stops after 3; BWD only skips 2-3 and reads T from memory.
-constexpr int kRW = 2;
-
-template <int NIT, bool FWD, bool BWD>
+template <int NIT, int RW, bool FWD, bool BWD>
 __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
     const float* __restrict__ q, const float* __restrict__ a,
     const float* __restrict__ top_in, const float* __restrict__ top_diff,
     float* __restrict__ top_out, float* __restrict__ dq, float* __restrict__ da, int N,
     int D4) {
-  extern __shared__ float4 lds4[];               // [4 waves][kRW * D4] squares
-  __shared__ float cs[4][kRW];
-  __shared__ double dens[4][kRW];
-  __shared__ double rcps[4][kRW];
-
+  constexpr int LPR = 64 / RW;                   // lanes per pair
+  extern __shared__ float4 lds4[];               // [4 waves][RW split images] (euclid_math.h)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row0 = (blockIdx.x * 4 + wave) * kRW;
+  const int row0 = (blockIdx.x * 4 + wave) * RW;
   if (row0 >= N) return;                         // whole wave leaves; no block barrier below
-  const int rows = min(kRW, N - row0);
+  const int rows = min(RW, N - row0);
   const int n4 = rows * D4;
   const size_t base4 = (size_t)row0 * D4;
   const float4* q4 = reinterpret_cast<const float4*>(q) + base4;
   const float4* a4 = reinterpret_cast<const float4*>(a) + base4;
-  float4* sq4 = lds4 + (size_t)wave * kRW * D4;
+  const int st4 = spec_stride4(D4);
+  float4* sq4 = lds4 + (size_t)wave * RW * st4;
 
   float4 x[NIT], y[NIT], df[NIT];
 #pragma unroll
@@ -72,6 +70,17 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
     x[it] = q4[ii];
     y[it] = a4[ii];
   }
+  // this lane's pair for the chain / coefficient work
+  const int grp = lane / LPR, j = lane % LPR;
+  const int grow = min(grp, rows - 1);           // a missing 2nd pair mirrors the 1st (results unused)
+  float T = 0.f;
+  if (!FWD) T = top_in[row0 + grow];
+  float g = 0.f;
+  if (BWD) g = top_diff[row0 + grow];
+
+  float pred[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) pred[r] = 0.f;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     df[it].x = x[it].x - y[it].x; df[it].y = x[it].y - y[it].y;
@@ -81,39 +90,55 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
       float4 s;
       s.x = df[it].x * df[it].x; s.y = df[it].y * df[it].y;
       s.z = df[it].z * df[it].z; s.w = df[it].w * df[it].w;
-      if (i < n4) sq4[i] = s;
+      // split-image slot of this float4 and its tree-sum contribution to the segment-0
+      // prediction of the pair it belongs to
+      const int r = (RW == 2 && i >= D4) ? 1 : 0;
+      const int ir = i - r * D4;
+      const bool seg0 = ir < spec_b4(D4);
+      if (i < n4) sq4[r * st4 + ir + (seg0 ? 0 : spec_h4(D4) - spec_b4(D4))] = s;
+      const float s4 = (i < n4 && seg0) ? (s.x + s.y) + (s.z + s.w) : 0.f;
+      pred[0] += (r == 0) ? s4 : 0.f;
+      if (RW == 2) pred[RW - 1] += (r == 1) ? s4 : 0.f;
     }
   }
-  wave_lds_sync();
-
-  if (lane < rows) {
-    float T;
-    if (FWD) {
-      const float dist = chain_sum_lds(sq4 + lane * D4, D4);
-      T = 1.0f / (1.0f + sqrtf(dist));          // :106-107
-      top_out[row0 + lane] = T;
-    } else {
-      T = top_in[row0 + lane];
+  if (FWD) {
+    // zero pad of each segment-0 image (0 or 1 entries)
+    if (lane < RW && spec_h4(D4) > spec_b4(D4))
+      sq4[lane * st4 + spec_b4(D4)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float mypred = 0.f;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const float p = wave_sum(pred[r]);
+      if (r == grow) mypred = p;
     }
-    if (BWD) {
-      const EuclidCoef k = euclid_coef(T, top_diff[row0 + lane]);
-      cs[wave][lane] = k.c;
-      dens[wave][lane] = k.den;
-      rcps[wave][lane] = k.rcp;
-    }
+    wave_lds_sync();
+#if defined(MMS_ABLATE) && MMS_ABLATE >= 1   // dev-only timing ablation (tools/ablate.sh): no chain
+    const float dist = mypred;
+#else
+    const float dist = chain_sum_speculative<LPR>(sq4 + grow * st4, D4, mypred, j, grp * LPR);
+#endif
+    T = 1.0f / (1.0f + sqrtf(dist));            // :106-107
+    if (j == 0 && grp < rows) top_out[row0 + grp] = T;
   }
   if (!BWD) return;
-  wave_lds_sync();
 
+  // coefficients of this lane group's pair, then of the pairs this lane's elements belong to
+  const EuclidCoef mine = euclid_coef(T, g);
+  EuclidCoef kr[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    kr[r].c = __shfl(mine.c, r * LPR, 64);
+    kr[r].den = __shfl(mine.den, r * LPR, 64);
+    kr[r].rcp = __shfl(mine.rcp, r * LPR, 64);
+  }
   float4* dq4 = reinterpret_cast<float4*>(dq) + base4;
   float4* da4 = reinterpret_cast<float4*>(da) + base4;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = lane + 64 * it;
     if (i >= n4) break;
-    const int r = i >= D4 ? 1 : 0;              // kRW == 2
-    EuclidCoef k;
-    k.c = cs[wave][r]; k.den = dens[wave][r]; k.rcp = rcps[wave][r];
+    EuclidCoef k = kr[0];
+    if (RW == 2 && i >= D4) k = kr[1];
     float4 t;
     t.x = euclid_tt(k, df[it].x); t.y = euclid_tt(k, df[it].y);
     t.z = euclid_tt(k, df[it].z); t.w = euclid_tt(k, df[it].w);
@@ -461,10 +486,13 @@ static bool vec4_ok(int D, const void* p0, const void* p1, const void* p2, const
 static size_t rows_lds_bytes(int D) { return (size_t)kRows * D * sizeof(float); }
 static bool rows_fit(int D) { return rows_lds_bytes(D) <= 64 * 1024; }
 
-// wave kernel: NIT = ceil(kRW * D/4 / 64) 16-byte loads per operand per lane.
-static int wave_nit(int D) { return (kRW * (D / 4) + 63) / 64; }
+// wave kernel: RW pairs per wave (2 up to D = 400, 1 beyond: the speculation
+// window in ulps must grow with sqrt(D), see euclid_math.h), NIT = ceil(RW*D/4 / 64)
+// 16-byte loads per operand per lane.
+static int wave_rw(int D) { return D <= 400 ? 2 : 1; }
+static int wave_nit(int D) { return (wave_rw(D) * (D / 4) + 63) / 64; }
 static bool wave_ok(int D, const void* p0, const void* p1, const void* p2, const void* p3) {
-  return vec4_ok(D, p0, p1, p2, p3) && wave_nit(D) <= 8;
+  return vec4_ok(D, p0, p1, p2, p3) && D <= 1024;
 }
 
 template <bool FWD, bool BWD>
@@ -472,18 +500,20 @@ static void launch_rows_wave(const float* q, const float* a, const float* top_in
                              const float* top_diff, float* top_out, float* dq, float* da, int N,
                              int D, hipStream_t s) {
   const int D4 = D / 4;
-  const unsigned grid = (unsigned)((N + 4 * kRW - 1) / (4 * kRW));
-  const size_t lds = FWD ? (size_t)4 * kRW * D4 * sizeof(float4) : 0;
-  switch (wave_nit(D)) {
-#define MMS_NIT_CASE(n)                                                                      \
-  case n:                                                                                    \
-    hipLaunchKernelGGL((euclid_rows_wave_kernel<n, FWD, BWD>), dim3(grid), dim3(256), lds, s, \
-                       q, a, top_in, top_diff, top_out, dq, da, N, D4);                      \
+  const int rw = wave_rw(D);
+  const unsigned grid = (unsigned)((N + 4 * rw - 1) / (4 * rw));
+  const size_t lds = FWD ? (size_t)4 * rw * 2 * (D4 - D4 / 2) * sizeof(float4) : 0;
+#define MMS_NIT_CASE(n, r)                                                                      \
+  case n:                                                                                       \
+    hipLaunchKernelGGL((euclid_rows_wave_kernel<n, r, FWD, BWD>), dim3(grid), dim3(256), lds, s, \
+                       q, a, top_in, top_diff, top_out, dq, da, N, D4);                         \
     break;
-    MMS_NIT_CASE(1) MMS_NIT_CASE(2) MMS_NIT_CASE(3) MMS_NIT_CASE(4)
-    MMS_NIT_CASE(5) MMS_NIT_CASE(6) MMS_NIT_CASE(7) MMS_NIT_CASE(8)
-#undef MMS_NIT_CASE
+  if (rw == 2) {
+    switch (wave_nit(D)) { MMS_NIT_CASE(1, 2) MMS_NIT_CASE(2, 2) MMS_NIT_CASE(3, 2) MMS_NIT_CASE(4, 2) }
+  } else {
+    switch (wave_nit(D)) { MMS_NIT_CASE(1, 1) MMS_NIT_CASE(2, 1) MMS_NIT_CASE(3, 1) MMS_NIT_CASE(4, 1) }
   }
+#undef MMS_NIT_CASE
 }
 
 int simcross_elementwise_forward(int mode, int N, int W1, int W2, int D,

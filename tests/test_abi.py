@@ -37,7 +37,7 @@ def test_workspace_queries_are_host_only(hiplib):
     assert need >= 2 * 16384 * 300 * 4
     assert hiplib.mms_simcross_workspace_bytes(7, 1, 1, 1, 1, 1) == 0       # bad mode
     assert hiplib.mms_pairrank_workspace_bytes(4096) in (0, 16)
-    assert hiplib.mms_triplet_workspace_bytes(4096) == 4096 // 2 * 4
+    assert hiplib.mms_triplet_workspace_bytes(4096) == 4096 * 4
     assert hiplib.mms_simmatrix_workspace_bytes(16384, 300, 300) > 16384 * 300 * 4
 
 

@@ -43,6 +43,10 @@ EUCLID_SHAPES = [
     (2, 40, 40, 50),     # the reference's network_v4 geometry (do_trec_qa_clean.py:468)
     (3, 41, 9, 33),      # tile remainders
     (2, 1, 6, 20),
+    (33, 1, 1, 1024),    # BASELINE cfg 5 width: one pair per wave, +-31 ulp window
+    (9, 1, 1, 400),      # last D with two pairs per wave
+    (9, 1, 1, 404),      # first D with one pair per wave
+    (3, 1, 1, 1028),     # beyond the wave kernel: generic rows kernel
 ]
 
 
@@ -75,6 +79,49 @@ def test_euclid_forward_backward_bitexact(shape, oracle, hiplib):
     assert_bitexact(host(top2), top_ref, "fused top")
     assert_bitexact(host(gq2), dq_ref, "fused dq")
     assert_bitexact(host(ga2), da_ref, "fused da")
+
+
+@pytest.mark.parametrize("D", [300, 1024])
+def test_euclid_speculation_miss_falls_back_exactly(D, oracle, hiplib):
+    """Adversarial rows for the speculative chain (euclid_math.h): one large square
+    followed by squares below half an ulp of the running sum.  The sequential fp32
+    sum swallows every small term while a tree sum keeps them, so the prediction is
+    tens of ulps off, the candidate window misses and the kernel must re-walk the
+    segment -- still bit-identical to the reference order."""
+    from mms_answer_selection_amd import capi
+    N = 6
+    q = np.zeros((N, 1, D), np.float32)
+    a = np.zeros((N, 1, D), np.float32)
+    tiny = np.float32(2.0 ** -12.5)
+    q[:, 0, 0] = 1.0
+    q[0:2, 0, 1:] = tiny                    # small terms in both segments
+    q[2:4, 0, 1:D // 2] = tiny              # only in segment 0
+    q[4, 0, 1:] = -tiny
+    a[5, 0, :] = rng(3).standard_normal(D).astype(np.float32)   # an ordinary row alongside
+    dT = rng(4).standard_normal((N, 1, 1, 1)).astype(np.float32)
+    top_ref, _, _ = oracle.simcross_forward(1, q, a)
+    # the construction really defeats the prediction: tree and sequential sums differ by > 15 ulp
+    sq = ((q - a)[0, 0, : (D // 4 // 2) * 4] ** 2).astype(np.float32)
+    seq = np.float32(0)
+    for v in sq:
+        seq = np.float32(seq + v)
+    tree = np.float32(sq.astype(np.float64).sum())
+    assert abs(int(tree.view(np.int32)) - int(seq.view(np.int32))) > (31 if D > 400 else 15)
+    dq_ref, da_ref, _, _ = oracle.simcross_backward(1, q, a, top_ref, dT)
+    top, gq, ga = nan_like(top_ref.shape), nan_like(q.shape), nan_like(a.shape)
+    capi.simcross_forward_backward(1, dev(q), dev(a), dev(dT), top, gq, ga)
+    assert_bitexact(host(top), top_ref, "top")
+    assert_bitexact(host(gq), dq_ref, "dq")
+    assert_bitexact(host(ga), da_ref, "da")
+    # the fused triplet step shares the scheme
+    y = np.ones((N, 1), np.float32)
+    sp, _, _ = oracle.simcross_forward(1, q, a)
+    out = dict(s_pos=nan_like((N, 1)), s_neg=nan_like((N, 1)), loss=nan_like((1,)),
+               dq=nan_like(q.shape), da_pos=nan_like(q.shape), da_neg=nan_like(q.shape))
+    capi.triplet_euclid_step(dev(q), dev(a), dev(a[::-1].copy()), dev(y), **out)
+    assert_bitexact(host(out["s_pos"]).ravel(), sp.ravel(), "triplet s_pos")
+    sn, _, _ = oracle.simcross_forward(1, q, a[::-1].copy())
+    assert_bitexact(host(out["s_neg"]).ravel(), sn.ravel(), "triplet s_neg")
 
 
 def test_euclid_unaligned_views_take_scalar_path(oracle, hiplib):
@@ -260,7 +307,7 @@ def test_pairrank(cfg, oracle, hiplib):
 # --------------------------------------------------------------------------- #
 # Fused (q, a+, a-) step == layer-by-layer oracle
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("cfg", [(8, 300), (4096, 300), (77, 301), (5, 4)])
+@pytest.mark.parametrize("cfg", [(8, 300), (4096, 300), (77, 301), (5, 4), (19, 1024), (7, 400)])
 def test_triplet_step(cfg, oracle, hiplib):
     from mms_answer_selection_amd import capi
     N, D = cfg
