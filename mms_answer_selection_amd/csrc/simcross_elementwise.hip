@@ -448,15 +448,129 @@ __global__ __launch_bounds__(256) void cross_bwd_kernel(
   }
 }
 
+// Tiled backward for general W1 x W2 (the fast path when the per-pair tables fit
+// LDS).  One workgroup per (pair, 32-wide d chunk):
+//   * per-(j,k) coefficient tables are built ONCE per workgroup in LDS
+//     (Euclid: c, den, 1/den; cosine: g, 1/(n0 n1), T/n0^2, T/n1^2);
+//   * the q / a chunk is staged in LDS (stride 33: conflict-free);
+//   * a thread owns one (j,d) of dq and walks k ascending, then one (k,d) of da
+//     walking j ascending -- the reference's accumulation order (:209-223).
+// Euclid stays bit-exact (euclid_tt's self-checking reciprocal path).  Cosine
+// multiplies by precomputed reciprocals instead of dividing per term: it is
+// held to 1e-5 like everything that is BLAS-ordered in the reference.
+constexpr int kBwdDC = 32;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void cross_bwd_tiled_kernel(
+    const float* __restrict__ q, const float* __restrict__ a,
+    const float* __restrict__ top, const float* __restrict__ top_diff,
+    const float* __restrict__ norm0, const float* __restrict__ norm1,
+    float* __restrict__ dq, float* __restrict__ da, int W1, int W2, int D, int nchunks) {
+  extern __shared__ double lds_d[];
+  constexpr int LS = kBwdDC + 1;
+  const int n = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+  const int d0 = chunk * kBwdDC, dn = min(kBwdDC, D - d0);
+  const int JK = W1 * W2;
+  // carve: doubles first (8-byte aligned), then floats
+  double* t_den = lds_d;                          // MODE 1: [JK]
+  double* t_rcp = lds_d + (MODE == 1 ? JK : 0);   // MODE 1: [JK]
+  float* fbase = reinterpret_cast<float*>(lds_d + (MODE == 1 ? 2 * JK : 0));
+  float* t_c = fbase;                             // MODE 1: c       MODE 0: g
+  float* t_i01 = fbase + JK;                      // MODE 0: 1/(n0 n1)
+  float* t_b1 = fbase + 2 * JK;                   // MODE 0: T/n0^2
+  float* t_b2 = fbase + 3 * JK;                   // MODE 0: T/n1^2
+  float* qs = fbase + (MODE == 1 ? JK : 4 * JK);
+  float* as = qs + W1 * LS;
+
+  const float* qn = q + (size_t)n * W1 * D;
+  const float* an = a + (size_t)n * W2 * D;
+  const float* Tn = top + (size_t)n * JK;
+  const float* gn = top_diff + (size_t)n * JK;
+
+  for (int e = threadIdx.x; e < JK; e += 256) {
+    if (MODE == 1) {
+      const EuclidCoef k = euclid_coef(Tn[e], gn[e]);
+      t_c[e] = k.c; t_den[e] = k.den; t_rcp[e] = k.rcp;
+    } else {
+      const int j = e / W2, kk = e - j * W2;
+      const float n0 = norm0[(size_t)n * W1 + j], n1 = norm1[(size_t)n * W2 + kk];
+      t_c[e] = gn[e];
+      t_i01[e] = 1.0f / n0 / n1;
+      t_b1[e] = Tn[e] / (n0 * n0);
+      t_b2[e] = Tn[e] / (n1 * n1);
+    }
+  }
+  for (int e = threadIdx.x; e < W1 * kBwdDC; e += 256) {
+    const int j = e >> 5, dd = e & 31;
+    qs[j * LS + dd] = dd < dn ? qn[(size_t)j * D + d0 + dd] : 0.f;
+  }
+  for (int e = threadIdx.x; e < W2 * kBwdDC; e += 256) {
+    const int k = e >> 5, dd = e & 31;
+    as[k * LS + dd] = dd < dn ? an[(size_t)k * D + d0 + dd] : 0.f;
+  }
+  __syncthreads();
+
+  float* dqn = dq + (size_t)n * W1 * D;
+  float* dan = da + (size_t)n * W2 * D;
+  for (int e = threadIdx.x; e < W1 * kBwdDC; e += 256) {
+    const int j = e >> 5, dd = e & 31;
+    if (dd >= dn) continue;
+    const float qv = qs[j * LS + dd];
+    float acc = 0.f;
+    for (int k = 0; k < W2; ++k) {
+      const int t = j * W2 + k;
+      const float av = as[k * LS + dd];
+      if (MODE == 1) {
+        EuclidCoef kc;
+        kc.c = t_c[t]; kc.den = t_den[t]; kc.rcp = t_rcp[t];
+        acc += euclid_tt(kc, qv - av);
+      } else {
+        acc += t_c[t] * (av * t_i01[t] - qv * t_b1[t]);
+      }
+    }
+    dqn[(size_t)j * D + d0 + dd] = acc;
+  }
+  for (int e = threadIdx.x; e < W2 * kBwdDC; e += 256) {
+    const int k = e >> 5, dd = e & 31;
+    if (dd >= dn) continue;
+    const float av = as[k * LS + dd];
+    float acc = 0.f;
+    for (int j = 0; j < W1; ++j) {
+      const int t = j * W2 + k;
+      const float qv = qs[j * LS + dd];
+      if (MODE == 1) {
+        EuclidCoef kc;
+        kc.c = t_c[t]; kc.den = t_den[t]; kc.rcp = t_rcp[t];
+        acc += -euclid_tt(kc, qv - av);
+      } else {
+        acc += t_c[t] * (qv * t_i01[t] - av * t_b2[t]);
+      }
+    }
+    dan[(size_t)k * D + d0 + dd] = acc;
+  }
+}
+
+static size_t cross_bwd_tiled_lds(int mode, int W1, int W2) {
+  const size_t JK = (size_t)W1 * W2;
+  const size_t tables = mode == 1 ? JK * (8 + 8 + 4) : JK * 16;
+  return tables + (size_t)(W1 + W2) * (kBwdDC + 1) * sizeof(float) + 16;
+}
+
 // ================================ dispatch ==================================
 
 template <int MODE>
 static void launch_cross_fwd(const float* q, const float* a, const float* n0,
                              const float* n1, float* top, int N, int W1, int W2,
                              int D, hipStream_t s) {
-  auto r_of = [](int w) { int r = (w + 7) / 8; return r > 5 ? 5 : r; };
-  const int rj = r_of(W1), rk = r_of(W2);
-  const int tilesJ = (W1 + 8 * rj - 1) / (8 * rj), tilesK = (W2 + 8 * rk - 1) / (8 * rk);
+  // Register tile per lane: as large as possible (fewer LDS reads per flop) while the
+  // launch still has enough waves to occupy the chip (small N: smaller tiles, more waves).
+  auto r_cap = [](int w, int cap) { int r = (w + 7) / 8; return r > cap ? cap : r; };
+  int rj = 1, rk = 1, tilesJ = 1, tilesK = 1;
+  for (int cap = 5; cap >= 1; --cap) {
+    rj = r_cap(W1, cap); rk = r_cap(W2, cap);
+    tilesJ = (W1 + 8 * rj - 1) / (8 * rj); tilesK = (W2 + 8 * rk - 1) / (8 * rk);
+    if ((long long)N * tilesJ * tilesK >= 1024) break;
+  }
   const long long work = (long long)N * tilesJ * tilesK;
   const unsigned grid = (unsigned)((work + 3) / 4);
 #define MMS_CROSS_CASE(J, K)                                                        \
@@ -578,6 +692,16 @@ int simcross_elementwise_backward(int mode, int N, int W1, int W2, int D,
       hipLaunchKernelGGL((cosine_rows_kernel<false, false, true>), dim3(grid), dim3(256), 0, s, q, a,
                          top_diff, const_cast<float*>(top), const_cast<float*>(norm0),
                          const_cast<float*>(norm1), dq, da, N, D);
+  } else if (cross_bwd_tiled_lds(mode, W1, W2) <= 64 * 1024 &&
+             (long long)N * ((D + kBwdDC - 1) / kBwdDC) <= 0x7fffffffLL) {
+    const int nchunks = (D + kBwdDC - 1) / kBwdDC;
+    const size_t lds = cross_bwd_tiled_lds(mode, W1, W2);
+    if (mode == 1)
+      hipLaunchKernelGGL((cross_bwd_tiled_kernel<1>), dim3((unsigned)(N * nchunks)), dim3(256), lds,
+                         s, q, a, top, top_diff, nullptr, nullptr, dq, da, W1, W2, D, nchunks);
+    else
+      hipLaunchKernelGGL((cross_bwd_tiled_kernel<0>), dim3((unsigned)(N * nchunks)), dim3(256), lds,
+                         s, q, a, top, top_diff, norm0, norm1, dq, da, W1, W2, D, nchunks);
   } else if (mode == 1) {
     hipLaunchKernelGGL((cross_bwd_kernel<1>), dim3(N), dim3(256), 0, s, q, a, top, top_diff,
                        nullptr, nullptr, dq, da, W1, W2, D);

@@ -47,6 +47,7 @@ EUCLID_SHAPES = [
     (9, 1, 1, 400),      # last D with two pairs per wave
     (9, 1, 1, 404),      # first D with one pair per wave
     (3, 1, 1, 1028),     # beyond the wave kernel: generic rows kernel
+    (1, 70, 60, 9),      # W1*W2 tables exceed LDS: generic cross backward
 ]
 
 
@@ -165,7 +166,7 @@ def test_backward_without_propagate_down_zeroes_both(hiplib):
 # SimCross cosine (dist_mode 0): 1e-5 (BLAS order in the reference)
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("shape", [(8, 1, 1, 300), (4096, 1, 1, 300), (9, 1, 1, 7),
-                                   (4, 5, 7, 300), (2, 40, 40, 50), (3, 41, 9, 33)])
+                                   (4, 5, 7, 300), (2, 40, 40, 50), (3, 41, 9, 33), (1, 70, 60, 9)])
 def test_cosine_forward_backward(shape, oracle, hiplib):
     from mms_answer_selection_amd import capi
     N, W1, W2, D = shape
