@@ -69,6 +69,34 @@ __device__ __forceinline__ float euclid_tt(const EuclidCoef& k, float diff) {
   return res;
 }
 
+// Four elements that share one coefficient set (a float4 of one pair's row):
+// same arithmetic as euclid_tt, but the rare-case tests are folded into ONE
+// wave-level branch per float4 and made cheaper:
+//   * "result could be float-subnormal" needs |num * rcp| < 2^-126; when
+//     |rcp| >= 1 (always true for T in (0,1]: |den| <= 1) that requires num
+//     itself to be subnormal -- one v_cmp_class per element; a pair whose
+//     |rcp| < 1 (only possible for caller-supplied T outside (0,1]) takes the
+//     exact path wholesale.
+__device__ __forceinline__ float4 euclid_tt4(const EuclidCoef& k, const float4& d) {
+  const float n0 = k.c * d.x, n1 = k.c * d.y, n2 = k.c * d.z, n3 = k.c * d.w;
+  const double p0 = (double)n0 * k.rcp, p1 = (double)n1 * k.rcp;
+  const double p2 = (double)n2 * k.rcp, p3 = (double)n3 * k.rcp;
+  float4 r;
+  r.x = (float)p0; r.y = (float)p1; r.z = (float)p2; r.w = (float)p3;
+  auto near = [](double p) {
+    const unsigned lo = (unsigned)__double_as_longlong(p) & 0x1fffffffu;
+    return (lo - 0x0fffffc0u) <= 128u;
+  };
+  auto subn = [](float x) -> bool { return __builtin_isfpclass(x, 0x0090 /* +-subnormal */); };
+  const bool risky = near(p0) || near(p1) || near(p2) || near(p3) || subn(n0) || subn(n1) ||
+                     subn(n2) || subn(n3) || !(fabs(k.rcp) >= 1.0);
+  if (risky) {
+    r.x = (float)((double)n0 / k.den); r.y = (float)((double)n1 / k.den);
+    r.z = (float)((double)n2 / k.den); r.w = (float)((double)n3 / k.den);
+  }
+  return r;
+}
+
 // s = init; for i in [0, n4): s += r4[i].x, .y, .z, .w  (fp32, adds only, in
 // that order) -- the reference's accumulation order for `dist += diff*diff`
 // (sim_cross_layer.cpp:100-105) once the squares are formed.  `r4` points at
@@ -114,60 +142,121 @@ __device__ __forceinline__ float chain_sum_lds(const float4* r4, int n4, float i
   return s;
 }
 
+// Packed variant: one v_pk_add_f32 advances TWO running sums (the two halves of
+// `s`) by the same addend.  op_sel picks which dword of the 64-bit source pair
+// feeds both halves, so no broadcast moves are needed.  Measured
+// (profiles/r01_chainbench…): ~10.5 ticks per dependent packed add however many
+// waves share the SIMD, against ~14 for a plain add at two waves per SIMD.
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pk_add_lo(float2v& s, const float2v& v) {   // s.xy += v.x
+  asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(s) : "v"(s), "v"(v));
+}
+__device__ __forceinline__ void pk_add_hi(float2v& s, const float2v& v) {   // s.xy += v.y
+  asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(s) : "v"(s), "v"(v));
+}
+__device__ __forceinline__ float2v chain_sum_lds_pk(const float4* r4, int n4, float2v init) {
+  float2v s = init;
+  auto step = [&](const float4& v) {
+    float2v lo, hi;
+    lo.x = v.x; lo.y = v.y; hi.x = v.z; hi.y = v.w;
+    pk_add_lo(s, lo); pk_add_hi(s, lo); pk_add_lo(s, hi); pk_add_hi(s, hi);
+  };
+  const int nb = n4 >> 3;
+  float4 va[8], vb[8];
+  if (nb > 0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) va[u] = r4[u];
+  }
+  int b = 0;
+  for (; b + 2 <= nb; b += 2) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) vb[u] = r4[(b + 1) * 8 + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) step(va[u]);
+    if (b + 2 < nb) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) va[u] = r4[(b + 2) * 8 + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) step(vb[u]);
+  }
+  if (b < nb) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) step(va[u]);
+  }
+  for (int d = nb * 8; d < n4; ++d) step(r4[d]);
+  return s;
+}
+
 // ---------------------------------------------------------------------------
-// Speculative two-segment evaluation of the d-ascending chain, bit-exact.
+// Speculative three-segment evaluation of the d-ascending chain, bit-exact.
 //
 // A dependent fp32 add costs ~6.6 cycles of latency and ~4.5 issue cycles of
 // its SIMD no matter how few lanes are active (profiles/r01_chainbench_*), so
 // a D-long chain per pair is the critical path of the forward pass.  The chain
-// cannot be re-associated (it must round like the reference), but its second
-// half can be started before the first half has finished if the value the
-// first half will end on is GUESSED: the sequential fp32 partial sum differs
-// from a tree sum of the same terms by a few ulps only (random-walk rounding
-// error, sigma ~ 0.22*sqrt(n) ulp; 2.3 ulp at n = 150).  So each pair gets
-// LPR = 64/RW lanes:
-//   lane j = 0        walks segment 0 from 0           (exact prefix),
-//   lane j = 1..LPR-1 walks segment 1 from pred + (j - LPR/2) ulps,
-// where pred is a tree sum of segment 0.  When lane 0 finishes, its end value
-// s1 selects the candidate lane whose start value IS s1 -- that lane has
-// computed exactly the reference's continuation.  If s1 fell outside the
-// window (never observed at +-15 ulps for D = 300: > 6 sigma) the segment is
-// simply re-walked from s1.  The result is the reference's sum bit for bit in
-// every case; only the time varies.
+// cannot be re-associated (it must round like the reference), but a later
+// segment can be started before the earlier ones have finished if the value
+// they will end on is GUESSED: the sequential fp32 partial sum differs from a
+// tree sum of the same terms by a few ulps only (random-walk rounding error,
+// sigma ~ 0.22*sqrt(n) ulp: 1.8 ulp at n = 100, 2.5 at n = 200, measured).
+// Each pair gets LPR = 64/RW lanes and, thanks to packed adds, 2*LPR running
+// sums ("slots"):
+//   lane 0                 walks segment 0 from 0                       (exact prefix)
+//   lanes 1 .. L1          walk segment 1 from pred1 + k ulps, |k| <= H1
+//   lanes L1+1 .. LPR-1    walk segment 2 from pred2 + k ulps, |k| <= H2
+// (LPR = 32: H1 = 12, H2 = 15; LPR = 64: H1 = 25, H2 = 36), where pred1/pred2
+// are tree sums of segment 0 / segments 0-1.  When the walks finish, the exact
+// end of segment 0 selects the segment-1 slot whose start value IS that end --
+// that slot has computed exactly the reference's continuation -- and its end
+// selects the segment-2 slot the same way.  A miss (the true value outside the
+// window; < 1e-6 per pair on embedding-like data, forced in the tests) re-walks
+// that segment from the exact value.  The result is the reference's sum bit for
+// bit in every case; only the time varies.
 //
-// LDS layout of one pair ("split image", spec_lds_index below): segment 0
-// = squares [0, b4) padded with all-zero float4 up to h4 = D4 - b4 entries,
-// then segment 1 = squares [b4, D4) (h4 entries).  Adding +0 to the
-// non-negative running sum is exact, so both kinds of lane run the same h4
-// steps with no predicate in the loop.
-__device__ __forceinline__ int spec_b4(int D4) { return D4 >> 1; }
-__device__ __forceinline__ int spec_h4(int D4) { return D4 - (D4 >> 1); }
-__device__ __forceinline__ int spec_stride4(int D4) { return 2 * spec_h4(D4); }
-// position of square-float4 `i` (0 <= i < D4) inside the pair's split image
-__device__ __forceinline__ int spec_lds_index(int i, int D4) {
-  return i < spec_b4(D4) ? i : i + (spec_h4(D4) - spec_b4(D4));
-}
+// LDS image of one pair: its D4 float4 squares followed by all-zero float4 up
+// to 3*h4, h4 = ceil(D4/3); segment g is [g*h4, (g+1)*h4).  Adding +0 to the
+// non-negative running sum is exact, so every lane runs the same h4 steps.
+__device__ __forceinline__ int spec_h4(int D4) { return (D4 + 2) / 3; }
+__device__ __forceinline__ int spec_stride4(int D4) { return 3 * spec_h4(D4); }
 
-// `img4`   this pair's split image in LDS (spec_stride4(D4) float4; the pad
-//          entries must already be zero)
-// `pred`   tree sum of segment 0 (any summation order; it only centres the window)
+template <int LPR> struct SpecPlan;
+template <> struct SpecPlan<32> { static constexpr int H1 = 12, L1 = 13, H2 = 15; };
+template <> struct SpecPlan<64> { static constexpr int H1 = 25, L1 = 26, H2 = 36; };
+
+// `img4`   this pair's image in LDS (pad entries already zero)
+// `pred1`, `pred2`  tree sums of segment 0 and of segments 0-1 (they only centre the windows)
 // `j`      this lane's index within the pair's lane group; `lead` = lane id of j = 0
 // returns  the full sum, valid in EVERY lane of the group.
 template <int LPR>
-__device__ __forceinline__ float chain_sum_speculative(const float4* img4, int D4, float pred,
-                                                       int j, int lead) {
+__device__ __forceinline__ float chain_sum_speculative(const float4* img4, int D4, float pred1,
+                                                       float pred2, int j, int lead) {
+  typedef SpecPlan<LPR> P;
   const int h4 = spec_h4(D4);
-  const bool exact_lane = (j == 0);
-  const float start = exact_lane ? 0.0f : __int_as_float(__float_as_int(pred) + (j - LPR / 2));
+  const int seg = (j == 0) ? 0 : (j <= P::L1 ? 1 : 2);
+  const int c0 = (seg == 1) ? 2 * (j - 1) - P::H1 : 2 * (j - 1 - P::L1) - P::H2;   // ulp offset of slot 0
+  const int pbits = __float_as_int(seg == 1 ? pred1 : pred2);
+  float2v start;
+  start.x = (seg == 0) ? 0.0f : __int_as_float(pbits + c0);
+  start.y = (seg == 0) ? 0.0f : __int_as_float(pbits + c0 + 1);
   __builtin_amdgcn_s_setprio(3);
-  const float end = chain_sum_lds(img4 + (exact_lane ? 0 : h4), h4, start);
-  const float s1 = __shfl(end, lead, 64);                       // exact prefix sum
-  const int k = __float_as_int(s1) - __float_as_int(pred) + LPR / 2;   // candidate lane index
-  const bool hit = (k >= 1) && (k <= LPR - 1);
-  float total = __shfl(end, lead + (hit ? k : 0), 64);
-  if (!hit) total = chain_sum_lds(img4 + h4, h4, s1);           // re-walk, exact
+  const float2v end = chain_sum_lds_pk(img4 + seg * h4, h4, start);
+  // segment 0 -> 1
+  const float s1 = __shfl(end.x, lead, 64);
+  const int k1 = __float_as_int(s1) - __float_as_int(pred1) + P::H1;     // slot index in segment 1
+  const bool hit1 = (k1 >= 0) && (k1 <= 2 * P::H1);
+  const int l1 = lead + 1 + ((hit1 ? k1 : 0) >> 1);
+  const float e1x = __shfl(end.x, l1, 64), e1y = __shfl(end.y, l1, 64);
+  float s2 = (k1 & 1) ? e1y : e1x;
+  if (!hit1) s2 = chain_sum_lds(img4 + h4, h4, s1);                       // re-walk, exact
+  // segment 1 -> 2
+  const int k2 = __float_as_int(s2) - __float_as_int(pred2) + P::H2;
+  const bool hit2 = (k2 >= 0) && (k2 <= 2 * P::H2);
+  const int l2 = lead + 1 + P::L1 + ((hit2 ? k2 : 0) >> 1);
+  const float e2x = __shfl(end.x, l2, 64), e2y = __shfl(end.y, l2, 64);
+  float s3 = (k2 & 1) ? e2y : e2x;
+  if (!hit2) s3 = chain_sum_lds(img4 + 2 * h4, h4, s2);
   __builtin_amdgcn_s_setprio(0);
-  return total;
+  return s3;
 }
 
 // Compiler-level ordering between LDS writes of some lanes and LDS reads of

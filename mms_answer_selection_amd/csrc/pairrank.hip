@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void triplet_wave_kernel(
     x[it] = q4[ii]; u[it] = p4[ii]; v[it] = m4[ii];
   }
   const float yy = y[row];
-  float predp = 0.f, predn = 0.f;
+  float predp1 = 0.f, predp2 = 0.f, predn1 = 0.f, predn2 = 0.f;
+  const int h4 = spec_h4(D4);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = lane + 64 * it;
@@ -179,24 +180,28 @@ __global__ __launch_bounds__(256) void triplet_wave_kernel(
     a.z = dp[it].z * dp[it].z; a.w = dp[it].w * dp[it].w;
     b.x = dn[it].x * dn[it].x; b.y = dn[it].y * dn[it].y;
     b.z = dn[it].z * dn[it].z; b.w = dn[it].w * dn[it].w;
-    if (i < D4) { const int li = spec_lds_index(i, D4); sqp[li] = a; sqn[li] = b; }
-    const bool seg0 = i < spec_b4(D4);
-    predp += seg0 ? (a.x + a.y) + (a.z + a.w) : 0.f;
-    predn += seg0 ? (b.x + b.y) + (b.z + b.w) : 0.f;
+    if (i < D4) { sqp[i] = a; sqn[i] = b; }
+    const float a4 = (i < D4) ? (a.x + a.y) + (a.z + a.w) : 0.f;
+    const float b4 = (i < D4) ? (b.x + b.y) + (b.z + b.w) : 0.f;
+    predp1 += (i < h4) ? a4 : 0.f; predp2 += (i < 2 * h4) ? a4 : 0.f;
+    predn1 += (i < h4) ? b4 : 0.f; predn2 += (i < 2 * h4) ? b4 : 0.f;
   }
-  if (lane < 2 && spec_h4(D4) > spec_b4(D4))
-    sqp[lane * st4 + spec_b4(D4)] = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const int npad = st4 - D4;                      // zero pad at the end of both images
+    if (lane < 2 * npad) sqp[(lane / npad) * st4 + D4 + (lane % npad)] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   const int br = lane >> 5, j = lane & 31;       // branch handled by this half-wave
   float dist;
   if (SPEC) {
-    predp = wave_sum(predp);
-    predn = wave_sum(predn);
+    predp1 = wave_sum(predp1); predp2 = wave_sum(predp2);
+    predn1 = wave_sum(predn1); predn2 = wave_sum(predn2);
     wave_lds_sync();
-    dist = chain_sum_speculative<32>(br ? sqn : sqp, D4, br ? predn : predp, j, br * 32);
+    dist = chain_sum_speculative<32>(br ? sqn : sqp, D4, br ? predn1 : predp1, br ? predn2 : predp2,
+                                     j, br * 32);
   } else {
     wave_lds_sync();
     dist = 0.f;
-    if (j == 0) {   // plain walk over both halves of the split image (the pad adds +0: exact)
+    if (j == 0) {   // plain walk over the whole image (the pad adds +0: exact)
       dist = chain_sum_lds(br ? sqn : sqp, st4, 0.f);
     }
     dist = __shfl(dist, br * 32, 64);
@@ -221,16 +226,12 @@ __global__ __launch_bounds__(256) void triplet_wave_kernel(
   for (int it = 0; it < NIT; ++it) {
     const int i = lane + 64 * it;
     if (i >= D4) break;
-    float tp[4], tn[4];
-    tp[0] = euclid_tt(k0, dp[it].x); tp[1] = euclid_tt(k0, dp[it].y);
-    tp[2] = euclid_tt(k0, dp[it].z); tp[3] = euclid_tt(k0, dp[it].w);
-    tn[0] = euclid_tt(k1, dn[it].x); tn[1] = euclid_tt(k1, dn[it].y);
-    tn[2] = euclid_tt(k1, dn[it].z); tn[3] = euclid_tt(k1, dn[it].w);
+    const float4 tp = euclid_tt4(k0, dp[it]), tn = euclid_tt4(k1, dn[it]);
     float4 oq, op, on;
-    oq.x = (0.f + tp[0]) + (0.f + tn[0]); oq.y = (0.f + tp[1]) + (0.f + tn[1]);
-    oq.z = (0.f + tp[2]) + (0.f + tn[2]); oq.w = (0.f + tp[3]) + (0.f + tn[3]);
-    op.x = 0.f + (-tp[0]); op.y = 0.f + (-tp[1]); op.z = 0.f + (-tp[2]); op.w = 0.f + (-tp[3]);
-    on.x = 0.f + (-tn[0]); on.y = 0.f + (-tn[1]); on.z = 0.f + (-tn[2]); on.w = 0.f + (-tn[3]);
+    oq.x = (0.f + tp.x) + (0.f + tn.x); oq.y = (0.f + tp.y) + (0.f + tn.y);
+    oq.z = (0.f + tp.z) + (0.f + tn.z); oq.w = (0.f + tp.w) + (0.f + tn.w);
+    op.x = 0.f + (-tp.x); op.y = 0.f + (-tp.y); op.z = 0.f + (-tp.z); op.w = 0.f + (-tp.w);
+    on.x = 0.f + (-tn.x); on.y = 0.f + (-tn.y); on.z = 0.f + (-tn.z); on.w = 0.f + (-tn.w);
     dq4[i] = oq;
     dp4[i] = op;
     dn4[i] = on;
@@ -330,7 +331,7 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
     const int nit = (D4 + 63) / 64;
     nparts = N;
     const unsigned grid = (unsigned)((N + 3) / 4);
-    const size_t lds = (size_t)4 * 2 * 2 * (D4 - D4 / 2) * sizeof(float4);
+    const size_t lds = (size_t)4 * 2 * 3 * ((D4 + 2) / 3) * sizeof(float4);
     const bool spec = D <= 400;   // +-15 ulp window: see euclid_math.h
 #define MMS_NIT_CASE(n)                                                                         \
   case n:                                                                                       \

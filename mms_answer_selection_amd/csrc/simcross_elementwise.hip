@@ -78,9 +78,10 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
   float g = 0.f;
   if (BWD) g = top_diff[row0 + grow];
 
-  float pred[RW];
+  float pred1[RW], pred2[RW];
 #pragma unroll
-  for (int r = 0; r < RW; ++r) pred[r] = 0.f;
+  for (int r = 0; r < RW; ++r) { pred1[r] = 0.f; pred2[r] = 0.f; }
+  const int h4 = spec_h4(D4);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     df[it].x = x[it].x - y[it].x; df[it].y = x[it].y - y[it].y;
@@ -90,32 +91,36 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
       float4 s;
       s.x = df[it].x * df[it].x; s.y = df[it].y * df[it].y;
       s.z = df[it].z * df[it].z; s.w = df[it].w * df[it].w;
-      // split-image slot of this float4 and its tree-sum contribution to the segment-0
-      // prediction of the pair it belongs to
+      // image slot of this float4 and its tree-sum contribution to the predictions of
+      // the pair it belongs to
       const int r = (RW == 2 && i >= D4) ? 1 : 0;
       const int ir = i - r * D4;
-      const bool seg0 = ir < spec_b4(D4);
-      if (i < n4) sq4[r * st4 + ir + (seg0 ? 0 : spec_h4(D4) - spec_b4(D4))] = s;
-      const float s4 = (i < n4 && seg0) ? (s.x + s.y) + (s.z + s.w) : 0.f;
-      pred[0] += (r == 0) ? s4 : 0.f;
-      if (RW == 2) pred[RW - 1] += (r == 1) ? s4 : 0.f;
+      if (i < n4) sq4[r * st4 + ir] = s;
+      const float s4 = (i < n4) ? (s.x + s.y) + (s.z + s.w) : 0.f;
+      const float c1 = (ir < h4) ? s4 : 0.f, c2 = (ir < 2 * h4) ? s4 : 0.f;
+      pred1[0] += (r == 0) ? c1 : 0.f;
+      pred2[0] += (r == 0) ? c2 : 0.f;
+      if (RW == 2) {
+        pred1[RW - 1] += (r == 1) ? c1 : 0.f;
+        pred2[RW - 1] += (r == 1) ? c2 : 0.f;
+      }
     }
   }
   if (FWD) {
-    // zero pad of each segment-0 image (0 or 1 entries)
-    if (lane < RW && spec_h4(D4) > spec_b4(D4))
-      sq4[lane * st4 + spec_b4(D4)] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float mypred = 0.f;
+    // zero pad at the end of each image (0..2 entries)
+    const int npad = st4 - D4;
+    if (lane < RW * npad) sq4[(lane / npad) * st4 + D4 + (lane % npad)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float my1 = 0.f, my2 = 0.f;
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-      const float p = wave_sum(pred[r]);
-      if (r == grow) mypred = p;
+      const float p1 = wave_sum(pred1[r]), p2 = wave_sum(pred2[r]);
+      if (r == grow) { my1 = p1; my2 = p2; }
     }
     wave_lds_sync();
 #if defined(MMS_ABLATE) && MMS_ABLATE >= 1   // dev-only timing ablation (tools/ablate.sh): no chain
-    const float dist = mypred;
+    const float dist = my2;
 #else
-    const float dist = chain_sum_speculative<LPR>(sq4 + grow * st4, D4, mypred, j, grp * LPR);
+    const float dist = chain_sum_speculative<LPR>(sq4 + grow * st4, D4, my1, my2, j, grp * LPR);
 #endif
     T = 1.0f / (1.0f + sqrtf(dist));            // :106-107
     if (j == 0 && grp < rows) top_out[row0 + grp] = T;
@@ -139,9 +144,7 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
     if (i >= n4) break;
     EuclidCoef k = kr[0];
     if (RW == 2 && i >= D4) k = kr[1];
-    float4 t;
-    t.x = euclid_tt(k, df[it].x); t.y = euclid_tt(k, df[it].y);
-    t.z = euclid_tt(k, df[it].z); t.w = euclid_tt(k, df[it].w);
+    const float4 t = euclid_tt4(k, df[it]);
     // dq = 0 + tt ; da = 0 + (-tt)   (:176-177 zero, :219-220 accumulate once)
     float4 o0, o1;
     o0.x = 0.f + t.x; o0.y = 0.f + t.y; o0.z = 0.f + t.z; o0.w = 0.f + t.w;
@@ -616,7 +619,7 @@ static void launch_rows_wave(const float* q, const float* a, const float* top_in
   const int D4 = D / 4;
   const int rw = wave_rw(D);
   const unsigned grid = (unsigned)((N + 4 * rw - 1) / (4 * rw));
-  const size_t lds = FWD ? (size_t)4 * rw * 2 * (D4 - D4 / 2) * sizeof(float4) : 0;
+  const size_t lds = FWD ? (size_t)4 * rw * 3 * ((D4 + 2) / 3) * sizeof(float4) : 0;
 #define MMS_NIT_CASE(n, r)                                                                      \
   case n:                                                                                       \
     hipLaunchKernelGGL((euclid_rows_wave_kernel<n, r, FWD, BWD>), dim3(grid), dim3(256), lds, s, \

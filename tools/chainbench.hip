@@ -23,6 +23,25 @@ __global__ void chain_regs(const float* in, float* out, unsigned long long* cyc,
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+// packed: one v_pk_add_f32 advances TWO independent chains per lane
+template <int ACTIVE>
+__global__ void chain_regs_pk(const float* in, float* out, unsigned long long* cyc, int reps) {
+  float2v v[32];
+  for (int i = 0; i < 32; ++i) { v[i].x = in[i]; v[i].y = in[i + 1]; }
+  float2v s; s.x = in[32]; s.y = in[33];
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if ((int)(threadIdx.x & 63) < ACTIVE) {
+    for (int r = 0; r < reps; ++r) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) s = s + v[i];
+    }
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 __global__ void chain_lds(const float* in, float* out, unsigned long long* cyc, int D4) {
   __shared__ float4 sq[4][256];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -58,6 +77,9 @@ int main() {
     hipLaunchKernelGGL(chain_regs<2>, dim3(256), dim3(256), 0, 0, in, out, cyc, reps); report("regs, 1 wave/SIMD all CUs, 2 lanes", 256, 320);
     hipLaunchKernelGGL(chain_regs<2>, dim3(512), dim3(256), 0, 0, in, out, cyc, reps); report("regs, 2 waves/SIMD all CUs, 2 lanes", 512, 320);
     hipLaunchKernelGGL(chain_regs<2>, dim3(1024), dim3(256), 0, 0, in, out, cyc, reps); report("regs, 4 waves/SIMD all CUs, 2 lanes", 1024, 320);
+    hipLaunchKernelGGL(chain_regs_pk<64>, dim3(1), dim3(64), 0, 0, in, out, cyc, reps); report("PACKED regs, 1 wave on chip", 1, 320);
+    hipLaunchKernelGGL(chain_regs_pk<64>, dim3(256), dim3(256), 0, 0, in, out, cyc, reps); report("PACKED regs, 1 wave/SIMD all CUs", 256, 320);
+    hipLaunchKernelGGL(chain_regs_pk<64>, dim3(512), dim3(256), 0, 0, in, out, cyc, reps); report("PACKED regs, 2 waves/SIMD all CUs", 512, 320);
     hipLaunchKernelGGL(chain_lds, dim3(1), dim3(64), 0, 0, in, out, cyc, 75); report("lds-fed D4=75, 1 wave", 1, 300);
     hipLaunchKernelGGL(chain_lds, dim3(512), dim3(256), 0, 0, in, out, cyc, 75); report("lds-fed D4=75, 2 waves/SIMD all CUs", 512, 300);
   }
