@@ -144,22 +144,19 @@ __device__ __forceinline__ float chain_sum_lds(const float4* r4, int n4, float i
 
 // Packed variant: one v_pk_add_f32 advances TWO running sums (the two halves of
 // `s`) by the same addend.  op_sel picks which dword of the 64-bit source pair
-// feeds both halves, so no broadcast moves are needed.  Measured
+// feeds both halves, so no broadcast moves are needed (plain vector code: hipcc
+// emits the op_sel forms itself and keeps its counted LDS waits).  Measured
 // (profiles/r01_chainbench…): ~10.5 ticks per dependent packed add however many
 // waves share the SIMD, against ~14 for a plain add at two waves per SIMD.
 typedef float float2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void pk_add_lo(float2v& s, const float2v& v) {   // s.xy += v.x
-  asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(s) : "v"(s), "v"(v));
-}
-__device__ __forceinline__ void pk_add_hi(float2v& s, const float2v& v) {   // s.xy += v.y
-  asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(s) : "v"(s), "v"(v));
-}
 __device__ __forceinline__ float2v chain_sum_lds_pk(const float4* r4, int n4, float2v init) {
   float2v s = init;
   auto step = [&](const float4& v) {
-    float2v lo, hi;
-    lo.x = v.x; lo.y = v.y; hi.x = v.z; hi.y = v.w;
-    pk_add_lo(s, lo); pk_add_hi(s, lo); pk_add_lo(s, hi); pk_add_hi(s, hi);
+    // hipcc lowers each line to one v_pk_add_f32 with op_sel broadcasting the addend
+    s = s + (float2v){v.x, v.x};
+    s = s + (float2v){v.y, v.y};
+    s = s + (float2v){v.z, v.z};
+    s = s + (float2v){v.w, v.w};
   };
   const int nb = n4 >> 3;
   float4 va[8], vb[8];
