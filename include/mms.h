@@ -175,6 +175,38 @@ int mms_triplet_euclid_step_f32(int N, int D, float margin, float loss_weight,
 
 size_t mms_triplet_workspace_bytes(int N);
 
+/* ------------------------------------------------------------------------- *
+ * Ranking metrics over the scores (forward only).  These
+ * define "ranking output": with the Euclidean scores bit-identical to the CPU
+ * code, MAP/MRR/AUC computed here are bit-identical too wherever the sort order
+ * is defined (ties between EQUAL scores are implementation-defined in the
+ * reference's unstable std::sort; here they keep original order).
+ * ------------------------------------------------------------------------- */
+
+/* Replaces MAPLayer<float>::Forward_cpu (src/caffe/layers/map_layer.cpp:41-100) and
+ * MRRLayer<float>::Forward_cpu (src/caffe/layers/mrr_layer.cpp:38-79).
+ * prob (n, fixed_axis+1): the score of item i is prob[i*(fixed_axis+1)+fixed_axis];
+ * label (n) in {0,1}; group (n): items are bucketed by int(group[i]).
+ * map_out / mrr_out / effective_out (device scalars) may each be NULL. */
+int mms_rank_map_mrr_f32(int n, int fixed_axis, const float* prob, const float* label,
+                         const float* group, float* map_out, float* mrr_out,
+                         int* effective_out, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* Replaces AUCLayer<float>::Forward_cpu (src/caffe/layers/auc_layer.cpp:47-136) for
+ * inner_num = 1: prob (n, dim), score = prob[i*dim + fixed_axis]. */
+int mms_rank_auc_f32(int n, int dim, int fixed_axis, const float* prob, const float* label,
+                     int has_ignore_label, int ignore_label, float* auc_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces RankAccuracyLayer<float>::Forward_cpu
+ * (src/caffe/layers/rank_accuracy_layer.cpp:36-50): mean of [label*(a-b) > 0]. */
+int mms_rank_accuracy_f32(int count, const float* a, const float* b, const float* label,
+                          float* acc_out, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+size_t mms_rank_workspace_bytes(int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,8 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmms_hip.so")
 LAYER_LIB = os.path.join(HERE, "libmms_caffe.so")
 
-HIP_SOURCES = ["mms_abi.hip", "simcross_elementwise.hip", "bilinear.hip", "pairrank.hip"]
-HIP_HEADERS = ["mms_common.h"]
+HIP_SOURCES = ["mms_abi.hip", "simcross_elementwise.hip", "bilinear.hip", "pairrank.hip", "ranking.hip"]
+HIP_HEADERS = ["mms_common.h", "euclid_math.h"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",

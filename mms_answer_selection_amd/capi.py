@@ -32,6 +32,10 @@ _SIGNATURES = {
     "mms_pairrank_backward_f32": (_i, [_i, _f] + [_vp] * 3 + [_i, _i] + [_vp] * 3),
     "mms_triplet_workspace_bytes": (_sz, [_i]),
     "mms_triplet_euclid_step_f32": (_i, [_i, _i, _f, _f] + [_vp] * 11 + [_sz, _vp]),
+    "mms_rank_workspace_bytes": (_sz, [_i]),
+    "mms_rank_map_mrr_f32": (_i, [_i, _i] + [_vp] * 7 + [_sz, _vp]),
+    "mms_rank_auc_f32": (_i, [_i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "mms_rank_accuracy_f32": (_i, [_i] + [_vp] * 5 + [_sz, _vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -187,3 +191,36 @@ def triplet_euclid_step(q, a_pos, a_neg, y, s_pos, s_neg, loss, dq, da_pos, da_n
         _ptr(a_neg, "a_neg"), _ptr(y, "y"), _ptr(s_pos, "s_pos"), _ptr(s_neg, "s_neg"),
         _ptr(loss, "loss"), _ptr(dq, "dq"), _ptr(da_pos, "da_pos"), _ptr(da_neg, "da_neg"),
         wsp, wsb, _stream()), "mms_triplet_euclid_step_f32")
+
+
+def rank_map_mrr(prob, label, group, fixed_axis=1, ws=None):
+    """-> (MAP, MRR, effective groups) as Python numbers (device -> host copy of 3 scalars)."""
+    n = label.numel()
+    wsp, wsb = (ws or _default_ws).get(lib().mms_rank_workspace_bytes(n), prob.device)
+    out = torch.empty(2, dtype=torch.float32, device=prob.device)
+    eff = torch.empty(1, dtype=torch.int32, device=prob.device)
+    check(lib().mms_rank_map_mrr_f32(
+        n, int(fixed_axis), _ptr(prob, "prob"), _ptr(label, "label"), _ptr(group, "group"),
+        out.data_ptr(), out.data_ptr() + 4, eff.data_ptr(), wsp, wsb, _stream()), "mms_rank_map_mrr_f32")
+    o = out.cpu().numpy()
+    return o[0], o[1], int(eff.item())
+
+
+def rank_auc(prob, label, fixed_axis=1, ignore_label=None, ws=None):
+    n = label.numel()
+    wsp, wsb = (ws or _default_ws).get(lib().mms_rank_workspace_bytes(n), prob.device)
+    out = torch.empty(1, dtype=torch.float32, device=prob.device)
+    check(lib().mms_rank_auc_f32(
+        n, int(prob.shape[1]), int(fixed_axis), _ptr(prob, "prob"), _ptr(label, "label"),
+        int(ignore_label is not None), int(ignore_label or 0), out.data_ptr(), wsp, wsb, _stream()),
+        "mms_rank_auc_f32")
+    return out.cpu().numpy()[0]
+
+
+def rank_accuracy(a, b, label, ws=None):
+    n = a.numel()
+    wsp, wsb = (ws or _default_ws).get(max(4096, lib().mms_rank_workspace_bytes(1)), a.device)
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    check(lib().mms_rank_accuracy_f32(n, _ptr(a, "a"), _ptr(b, "b"), _ptr(label, "label"),
+                                      out.data_ptr(), wsp, wsb, _stream()), "mms_rank_accuracy_f32")
+    return out.cpu().numpy()[0]

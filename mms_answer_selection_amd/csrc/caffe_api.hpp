@@ -249,6 +249,22 @@ struct PairRankLossParameter {  // caffe.proto:479-481
   float margin_ = 1.0f;
   float margin() const { return margin_; }
 };
+struct MAPParameter {  // caffe.proto:422-424
+  int fixed_axis_ = 1;
+  int fixed_axis() const { return fixed_axis_; }
+};
+struct MRRParameter {  // caffe.proto:426-428
+  int fixed_axis_ = 1;
+  int fixed_axis() const { return fixed_axis_; }
+};
+struct AUCParameter {  // caffe.proto:465-469
+  int fixed_axis_ = 1, axis_ = 1, ignore_label_ = 0;
+  bool has_ignore_label_ = false;
+  int fixed_axis() const { return fixed_axis_; }
+  int axis() const { return axis_; }
+  bool has_ignore_label() const { return has_ignore_label_; }
+  int ignore_label() const { return ignore_label_; }
+};
 struct ParamSpec {  // caffe.proto:281-308 (subset)
   string name;
   float lr_mult = 1, decay_mult = 1;
@@ -261,6 +277,12 @@ struct LayerParameter {  // caffe.proto:310-416 (subset)
   SimCrossParameter sim_cross_param_;
   SimMatrixParameter sim_matrix_param_;
   PairRankLossParameter pair_rank_loss_param_;
+  MAPParameter map_param_;
+  MRRParameter mrr_param_;
+  AUCParameter auc_param_;
+  const MAPParameter& map_param() const { return map_param_; }
+  const MRRParameter& mrr_param() const { return mrr_param_; }
+  const AUCParameter& auc_param() const { return auc_param_; }
   const string& name() const { return name_; }
   const string& type() const { return type_; }
   int bottom_size() const { return (int)bottom_.size(); }

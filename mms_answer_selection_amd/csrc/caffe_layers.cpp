@@ -325,6 +325,157 @@ class PairRankLossLayer : public LossLayer<Dtype> {
 INSTANTIATE_CLASS(PairRankLossLayer);
 REGISTER_LAYER_CLASS(PairRankLoss);
 
+// ===================== MAP / MRR / AUC / RankAccuracy (forward only) =========
+// Reference: src/caffe/layers/{map,mrr,auc,rank_accuracy}_layer.cpp and their headers.
+// The reference has no GPU code for these (Forward_gpu falls back to Forward_cpu through
+// the base class, i.e. a D2H copy of the whole score blob); here they run on the device.
+template <typename Dtype>
+class RankMetricLayerBase : public Layer<Dtype> {
+ public:
+  explicit RankMetricLayerBase(const LayerParameter& param) : Layer<Dtype>(param) {}
+  int ExactNumTopBlobs() const override { return 1; }
+ protected:
+  void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
+  // map_layer.cpp / mrr_layer.cpp / auc_layer.cpp: Backward is a no-op for metric layers
+  void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) override {}
+  void Backward_gpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) override {}
+  void size_workspace(int n) {
+    const size_t ws = mms_rank_workspace_bytes(n);
+    workspace_.Reshape(vector<int>{(int)((ws + sizeof(Dtype) - 1) / sizeof(Dtype))});
+  }
+  Blob<Dtype> workspace_;
+};
+
+template <typename Dtype>
+class MAPLayer : public RankMetricLayerBase<Dtype> {
+ public:
+  explicit MAPLayer(const LayerParameter& param) : RankMetricLayerBase<Dtype>(param) {}
+  const char* type() const override { return "MAP"; }
+  int ExactNumBottomBlobs() const override { return 3; }
+  void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    fixed_axis_ = this->layer_param_.map_param().fixed_axis();           // map_layer.cpp:13
+  }
+  void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    CHECK_LE(fixed_axis_, bottom[0]->count() / bottom[1]->count())
+        << "top_k must be less than or equal to the number of classes.";
+    const int outer = bottom[0]->count(0, 1), inner = bottom[0]->count(2);
+    CHECK_EQ(outer * inner, bottom[1]->count()) << "Number of labels must match number of predictions";
+    CHECK_EQ(outer * inner, bottom[2]->count());
+    top[0]->Reshape(vector<int>());
+    this->size_workspace(bottom[0]->num());
+  }
+ protected:
+  void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    mms_check(mms_rank_map_mrr_f32(bottom[0]->num(), fixed_axis_, bottom[0]->gpu_data(),
+                                   bottom[1]->gpu_data(), bottom[2]->gpu_data(),
+                                   top[0]->mutable_gpu_data(), nullptr, nullptr,
+                                   this->workspace_.mutable_gpu_data(),
+                                   (size_t)this->workspace_.count() * sizeof(Dtype), nullptr),
+              "mms_rank_map_mrr_f32");
+  }
+  int fixed_axis_ = 1;
+};
+INSTANTIATE_CLASS(MAPLayer);
+REGISTER_LAYER_CLASS(MAP);
+
+template <typename Dtype>
+class MRRLayer : public RankMetricLayerBase<Dtype> {
+ public:
+  explicit MRRLayer(const LayerParameter& param) : RankMetricLayerBase<Dtype>(param) {}
+  const char* type() const override { return "MRR"; }
+  int ExactNumBottomBlobs() const override { return 3; }
+  void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    fixed_axis_ = this->layer_param_.mrr_param().fixed_axis();           // mrr_layer.cpp:13
+  }
+  void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    CHECK_LE(fixed_axis_, bottom[0]->count() / bottom[1]->count())
+        << "top_k must be less than or equal to the number of classes.";
+    const int outer = bottom[0]->count(0, 1), inner = bottom[0]->count(2);
+    CHECK_EQ(outer * inner, bottom[1]->count()) << "Number of labels must match number of predictions";
+    CHECK_EQ(outer * inner, bottom[2]->count());
+    top[0]->Reshape(vector<int>());
+    this->size_workspace(bottom[0]->num());
+  }
+ protected:
+  void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    mms_check(mms_rank_map_mrr_f32(bottom[0]->num(), fixed_axis_, bottom[0]->gpu_data(),
+                                   bottom[1]->gpu_data(), bottom[2]->gpu_data(), nullptr,
+                                   top[0]->mutable_gpu_data(), nullptr,
+                                   this->workspace_.mutable_gpu_data(),
+                                   (size_t)this->workspace_.count() * sizeof(Dtype), nullptr),
+              "mms_rank_map_mrr_f32");
+  }
+  int fixed_axis_ = 1;
+};
+INSTANTIATE_CLASS(MRRLayer);
+REGISTER_LAYER_CLASS(MRR);
+
+template <typename Dtype>
+class AUCLayer : public RankMetricLayerBase<Dtype> {
+ public:
+  explicit AUCLayer(const LayerParameter& param) : RankMetricLayerBase<Dtype>(param) {}
+  const char* type() const override { return "AUC"; }
+  int ExactNumBottomBlobs() const override { return 2; }
+  int ExactNumTopBlobs() const override { return -1; }
+  int MinTopBlobs() const override { return 1; }
+  void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    const AUCParameter& p = this->layer_param_.auc_param();               // auc_layer.cpp:14-20
+    fixed_axis_ = p.fixed_axis();
+    has_ignore_label_ = p.has_ignore_label();
+    if (has_ignore_label_) ignore_label_ = p.ignore_label();
+  }
+  void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    CHECK_LE(fixed_axis_, bottom[0]->count() / bottom[1]->count())
+        << "top_k must be less than or equal to the number of classes.";
+    label_axis_ = bottom[0]->CanonicalAxisIndex(this->layer_param_.auc_param().axis());
+    outer_num_ = bottom[0]->count(0, label_axis_);
+    inner_num_ = bottom[0]->count(label_axis_ + 1);
+    CHECK_EQ(outer_num_ * inner_num_, bottom[1]->count()) << "Number of labels must match number of predictions";
+    CHECK_EQ(inner_num_, 1) << "AUC on the GPU is provided for inner_num == 1 (prob (N,C)), as the driver uses it";
+    top[0]->Reshape(vector<int>());
+    this->size_workspace(outer_num_);
+  }
+ protected:
+  void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    mms_check(mms_rank_auc_f32(outer_num_, bottom[0]->count() / outer_num_, fixed_axis_,
+                               bottom[0]->gpu_data(), bottom[1]->gpu_data(), has_ignore_label_,
+                               ignore_label_, top[0]->mutable_gpu_data(),
+                               this->workspace_.mutable_gpu_data(),
+                               (size_t)this->workspace_.count() * sizeof(Dtype), nullptr),
+              "mms_rank_auc_f32");
+  }
+  int fixed_axis_ = 1, label_axis_ = 1, outer_num_ = 0, inner_num_ = 1, ignore_label_ = 0;
+  bool has_ignore_label_ = false;
+};
+INSTANTIATE_CLASS(AUCLayer);
+REGISTER_LAYER_CLASS(AUC);
+
+template <typename Dtype>
+class RankAccuracyLayer : public RankMetricLayerBase<Dtype> {
+ public:
+  explicit RankAccuracyLayer(const LayerParameter& param) : RankMetricLayerBase<Dtype>(param) {}
+  const char* type() const override { return "RankAccuracy"; }
+  int ExactNumBottomBlobs() const override { return 3; }
+  int ExactNumTopBlobs() const override { return -1; }
+  int MinTopBlobs() const override { return 1; }
+  void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    CHECK_EQ(bottom[0]->count(), bottom[1]->count()) << "two pairs have the same dimension!.";
+    CHECK_EQ(bottom[0]->count(), bottom[2]->count()) << "pair should have the same dimension with the label!.";
+    top[0]->Reshape(vector<int>());
+    this->size_workspace(1);
+  }
+ protected:
+  void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    mms_check(mms_rank_accuracy_f32(bottom[0]->count(), bottom[0]->gpu_data(), bottom[1]->gpu_data(),
+                                    bottom[2]->gpu_data(), top[0]->mutable_gpu_data(),
+                                    this->workspace_.mutable_gpu_data(),
+                                    (size_t)this->workspace_.count() * sizeof(Dtype), nullptr),
+              "mms_rank_accuracy_f32");
+  }
+};
+INSTANTIATE_CLASS(RankAccuracyLayer);
+REGISTER_LAYER_CLASS(RankAccuracy);
+
 // ============================ prototxt (text format) subset ==================
 namespace {
 struct Tok {
@@ -488,6 +639,26 @@ class Parser {
     if (n == "sim_matrix_param") {
       return message([&](const string& m) {
         if (m == "weight_filler") return filler(&lp->sim_matrix_param_.weight_filler_);
+        return false;
+      });
+    }
+    if (n == "map_param" || n == "mrr_param") {
+      int* fa = n == "map_param" ? &lp->map_param_.fixed_axis_ : &lp->mrr_param_.fixed_axis_;
+      return message([&](const string& m) {
+        Tok w;
+        if (!scalar(&w)) return false;
+        if (m == "fixed_axis") return as_int(w, fa);
+        return false;
+      });
+    }
+    if (n == "auc_param") {
+      AUCParameter* p = &lp->auc_param_;
+      return message([&](const string& m) {
+        Tok w;
+        if (!scalar(&w)) return false;
+        if (m == "fixed_axis") return as_int(w, &p->fixed_axis_);
+        if (m == "axis") return as_int(w, &p->axis_);
+        if (m == "ignore_label") { p->has_ignore_label_ = true; return as_int(w, &p->ignore_label_); }
         return false;
       });
     }

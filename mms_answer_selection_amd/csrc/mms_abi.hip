@@ -41,6 +41,15 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
                         const float* ap, const float* an, const float* y, float* s_pos,
                         float* s_neg, float* loss, float* dq, float* dap, float* dan, void* ws,
                         size_t ws_bytes, hipStream_t s);
+// ranking.hip
+size_t rank_workspace_bytes(int n);
+int rank_map_mrr(int n, int fixed_axis, const float* prob, const float* label, const float* group,
+                 float* map_out, float* mrr_out, int* effective, void* ws, size_t ws_bytes,
+                 hipStream_t s);
+int rank_auc(int n, int dim, int fixed_axis, const float* prob, const float* label, int has_ignore,
+             int ignore_label, float* auc_out, void* ws, size_t ws_bytes, hipStream_t s);
+int rank_accuracy(int count, const float* a, const float* b, const float* label, float* out,
+                  void* ws, size_t ws_bytes, hipStream_t s);
 }  // namespace mms
 
 using namespace mms;
@@ -209,6 +218,36 @@ int mms_triplet_euclid_step_f32(int N, int D, float margin, float loss_weight, c
     return MMS_ERR_INVALID_ARG;
   return triplet_euclid_step(N, D, margin, loss_weight, q, a_pos, a_neg, y, s_pos, s_neg, loss,
                              dq, da_pos, da_neg, workspace, workspace_bytes, as_stream(stream));
+}
+
+size_t mms_rank_workspace_bytes(int n) { return n > 0 ? rank_workspace_bytes(n) : 0; }
+
+int mms_rank_map_mrr_f32(int n, int fixed_axis, const float* prob, const float* label,
+                         const float* group, float* map_out, float* mrr_out, int* effective_out,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (n <= 0 || fixed_axis < 0 || (long long)n * (fixed_axis + 1) > 0x7fffffffLL)
+    return MMS_ERR_INVALID_ARG;
+  if (!prob || !label || !group) return MMS_ERR_INVALID_ARG;
+  return rank_map_mrr(n, fixed_axis, prob, label, group, map_out, mrr_out, effective_out,
+                      workspace, workspace_bytes, as_stream(stream));
+}
+
+int mms_rank_auc_f32(int n, int dim, int fixed_axis, const float* prob, const float* label,
+                     int has_ignore_label, int ignore_label, float* auc_out, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  if (n <= 0 || dim <= 0 || fixed_axis < 0 || fixed_axis >= dim ||
+      (long long)n * dim > 0x7fffffffLL)
+    return MMS_ERR_INVALID_ARG;
+  if (!prob || !label || !auc_out) return MMS_ERR_INVALID_ARG;
+  return rank_auc(n, dim, fixed_axis, prob, label, has_ignore_label, ignore_label, auc_out,
+                  workspace, workspace_bytes, as_stream(stream));
+}
+
+int mms_rank_accuracy_f32(int count, const float* a, const float* b, const float* label,
+                          float* acc_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (count <= 0) return MMS_ERR_INVALID_ARG;
+  if (!a || !b || !label || !acc_out) return MMS_ERR_INVALID_ARG;
+  return rank_accuracy(count, a, b, label, acc_out, workspace, workspace_bytes, as_stream(stream));
 }
 
 }  // extern "C"

@@ -1,0 +1,229 @@
+// csrc/ranking.hip -- the forward-only ranking metrics that consume the scores
+// of the hot path: MAP, MRR, AUC, RankAccuracy.
+//
+// Reference:
+//   MAPLayer::Forward_cpu            src/caffe/layers/map_layer.cpp:41-100
+//   MRRLayer::Forward_cpu            src/caffe/layers/mrr_layer.cpp:38-79
+//   AUCLayer::Forward_cpu            src/caffe/layers/auc_layer.cpp:47-136
+//   RankAccuracyLayer::Forward_cpu   src/caffe/layers/rank_accuracy_layer.cpp:36-50
+// The reference buckets items by int(group) in a std::map (ascending group
+// id), std::sort's each bucket by score descending, and walks it
+// sequentially.  Here: one 64-bit radix sort (rocPRIM) on
+//   key = (group id, biased to unsigned) << 32 | order-reversed score bits
+// gives "group ascending, score descending" for all buckets at once; one thread
+// per bucket then walks its items and one thread folds the buckets in group
+// order, both with the reference's float expressions (`ap += ++rank/(i+1)`,
+// `mrr += 1.0/(rank+1)` through double, ...), so MAP/MRR/AUC are bit-identical
+// to the CPU code whenever the order is defined.  Ties: std::sort is unstable,
+// so the reference's order among EQUAL scores is implementation-defined; the
+// radix sort is stable (original index ascending).  Results can differ from a
+// particular libstdc++ only when equal scores carry different labels.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "mms_common.h"
+
+namespace mms {
+
+__device__ __forceinline__ unsigned desc_bits(float s) {
+  unsigned u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending total order
+  return ~u;                                         // descending
+}
+
+__global__ __launch_bounds__(256) void rank_keys_kernel(int n, int stride, int offset,
+                                                        const float* __restrict__ prob,
+                                                        const float* __restrict__ group,
+                                                        unsigned long long* __restrict__ keys,
+                                                        unsigned* __restrict__ vals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned g = group ? (unsigned)((int)group[i]) + 0x80000000u : 0u;   // map<int,...> key order
+  keys[i] = ((unsigned long long)g << 32) | desc_bits(prob[(size_t)i * stride + offset]);
+  vals[i] = (unsigned)i;
+}
+
+// One thread per sorted position; the thread at a bucket's first position walks the
+// bucket (map_layer.cpp:76-96, mrr_layer.cpp:57-75).  flags bit 0: the bucket counts
+// for MAP (a label == 1 and a label != 1 present, :80-92); bit 1: it counts for MRR
+// (a label == 1 and a label == 0 present, mrr_layer.cpp:61-73).
+__global__ __launch_bounds__(256) void rank_bucket_kernel(int n,
+                                                          const unsigned long long* __restrict__ keys,
+                                                          const unsigned* __restrict__ vals,
+                                                          const float* __restrict__ label,
+                                                          float* __restrict__ ap_out,
+                                                          int* __restrict__ rank_out,
+                                                          int* __restrict__ flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned g = (unsigned)(keys[i] >> 32);
+  int fl = 0;
+  if (i == 0 || (unsigned)(keys[i - 1] >> 32) != g) {
+    float ap = 0.f;
+    int map_rank = 0, not_one = 0, zero = 0, mrr_rank = -1;
+    for (int p = i; p < n && (unsigned)(keys[p] >> 32) == g; ++p) {
+      const int lab = (int)label[vals[p]];
+      const int pos = p - i;
+      if (lab == 1) {
+        ap += (++map_rank) / (float)(pos + 1);
+        if (mrr_rank < 0) mrr_rank = pos;
+      } else {
+        not_one = 1;
+        if (lab == 0) zero = 1;
+      }
+    }
+    if (map_rank >= 1 && not_one) { fl |= 1; ap_out[i] = ap / map_rank; }
+    if (mrr_rank >= 0 && zero) { fl |= 2; rank_out[i] = mrr_rank; }
+  }
+  flags[i] = fl;
+}
+
+// Folds the buckets in sorted (= ascending group id) order with the reference's
+// running sums.  One thread: n is an evaluation split (thousands), not a batch.
+__global__ void rank_fold_kernel(int n, const float* __restrict__ ap, const int* __restrict__ rank,
+                                 const int* __restrict__ flags, float* __restrict__ map_out,
+                                 float* __restrict__ mrr_out, int* __restrict__ effective) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  float map_ = 0.f, mrr = 0.f;
+  int eff_map = 0, eff_mrr = 0;
+  for (int i = 0; i < n; ++i) {
+    const int fl = flags[i];
+    if (fl & 1) { ++eff_map; map_ += ap[i]; }                       // map_layer.cpp:93-94
+    // mrr += 1.0/(mrr_rank+1): float + double, stored back to float (mrr_layer.cpp:75)
+    if (fl & 2) { ++eff_mrr; mrr = (float)((double)mrr + 1.0 / (rank[i] + 1)); }
+  }
+  if (map_out) *map_out = map_ / eff_map;   // NaN when no bucket counts, like the reference (:99)
+  if (mrr_out) *mrr_out = mrr / eff_mrr;
+  if (effective) *effective = eff_map;
+}
+
+// AUC: global descending sort, then the reference's sequential walk (auc_layer.cpp:119-134).
+__global__ void auc_fold_kernel(int n, const unsigned* __restrict__ vals,
+                                const float* __restrict__ label, int has_ignore, int ignore_label,
+                                float* __restrict__ auc_out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  float auc = 0.f;
+  int high = 0, count = 0;
+  for (int i = 0; i < n; ++i) {
+    const int lab = (int)label[vals[i]];
+    if (has_ignore && lab == ignore_label) continue;   // :68-70 (skipped items keep their order)
+    ++count;
+    high += lab;
+    auc += high * (1 - lab);
+  }
+  *auc_out = high > 0 ? auc / high / (count - high) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void rank_accuracy_kernel(int count, const float* __restrict__ a,
+                                                            const float* __restrict__ b,
+                                                            const float* __restrict__ label,
+                                                            unsigned* __restrict__ partial) {
+  __shared__ unsigned red[4];
+  unsigned c = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256)
+    c += (label[i] * (a[i] - b[i])) > 0 ? 1u : 0u;      // :45
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void rank_accuracy_finish_kernel(int blocks, int count, const unsigned* __restrict__ partial,
+                                            float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  unsigned long long c = 0;
+  for (int i = 0; i < blocks; ++i) c += partial[i];
+  // the reference accumulates 0/1 into a float: exact up to 2^24, then it sticks
+  float acc = c > 16777216ull ? 16777216.f : (float)c;
+  *out = acc / count;
+}
+
+// ------------------------------- workspace layout ---------------------------
+struct RankWs {
+  size_t keys0, keys1, vals0, vals1, ap, rr, flags, temp, total;
+};
+static RankWs rank_ws(int n) {
+  RankWs w{};
+  size_t o = 0;
+  auto take = [&](size_t b) { size_t at = o; o += round_up(b, 256); return at; };
+  w.keys0 = take((size_t)n * 8); w.keys1 = take((size_t)n * 8);
+  w.vals0 = take((size_t)n * 4); w.vals1 = take((size_t)n * 4);
+  w.ap = take((size_t)n * 4); w.rr = take((size_t)n * 4); w.flags = take((size_t)n * 4);
+  w.temp = o;
+  w.total = o + (size_t)n * 8 + (4u << 20);   // generous bound for rocPRIM's scratch; checked at run time
+  return w;
+}
+size_t rank_workspace_bytes(int n) { return rank_ws(n).total; }
+
+static int sort_pairs(const RankWs& lay, char* base, size_t ws_bytes, int n, unsigned bits,
+                      hipStream_t s) {
+  auto* k0 = reinterpret_cast<unsigned long long*>(base + lay.keys0);
+  auto* k1 = reinterpret_cast<unsigned long long*>(base + lay.keys1);
+  auto* v0 = reinterpret_cast<unsigned*>(base + lay.vals0);
+  auto* v1 = reinterpret_cast<unsigned*>(base + lay.vals1);
+  size_t need = 0;
+  if (rocprim::radix_sort_pairs(nullptr, need, k0, k1, v0, v1, (size_t)n, 0u, bits, s) != hipSuccess)
+    return MMS_ERR_LAUNCH;
+  if (lay.temp + need > ws_bytes) return MMS_ERR_WORKSPACE;
+  if (rocprim::radix_sort_pairs(base + lay.temp, need, k0, k1, v0, v1, (size_t)n, 0u, bits, s) !=
+      hipSuccess)
+    return MMS_ERR_LAUNCH;
+  return MMS_OK;
+}
+
+int rank_map_mrr(int n, int fixed_axis, const float* prob, const float* label, const float* group,
+                 float* map_out, float* mrr_out, int* effective, void* ws, size_t ws_bytes,
+                 hipStream_t s) {
+  const RankWs lay = rank_ws(n);
+  if (!ws || ws_bytes < lay.temp) return MMS_ERR_WORKSPACE;
+  char* base = static_cast<char*>(ws);
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  // score of item i: prob[i*(fixed_axis+1) + fixed_axis]  (map_layer.cpp:50, mrr_layer.cpp:49)
+  hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(256), 0, s, n, fixed_axis + 1, fixed_axis,
+                     prob, group, reinterpret_cast<unsigned long long*>(base + lay.keys0),
+                     reinterpret_cast<unsigned*>(base + lay.vals0));
+  int rc = sort_pairs(lay, base, ws_bytes, n, 64u, s);
+  if (rc != MMS_OK) return rc;
+  auto* keys = reinterpret_cast<unsigned long long*>(base + lay.keys1);
+  auto* vals = reinterpret_cast<unsigned*>(base + lay.vals1);
+  hipLaunchKernelGGL(rank_bucket_kernel, dim3(grid), dim3(256), 0, s, n, keys, vals, label,
+                     reinterpret_cast<float*>(base + lay.ap), reinterpret_cast<int*>(base + lay.rr),
+                     reinterpret_cast<int*>(base + lay.flags));
+  hipLaunchKernelGGL(rank_fold_kernel, dim3(1), dim3(64), 0, s, n,
+                     reinterpret_cast<float*>(base + lay.ap), reinterpret_cast<int*>(base + lay.rr),
+                     reinterpret_cast<int*>(base + lay.flags), map_out, mrr_out, effective);
+  return launch_status();
+}
+
+int rank_auc(int n, int dim, int fixed_axis, const float* prob, const float* label, int has_ignore,
+             int ignore_label, float* auc_out, void* ws, size_t ws_bytes, hipStream_t s) {
+  const RankWs lay = rank_ws(n);
+  if (!ws || ws_bytes < lay.temp) return MMS_ERR_WORKSPACE;
+  char* base = static_cast<char*>(ws);
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  // score of item i: prob[i*dim + fixed_axis]  (auc_layer.cpp:75-76 with inner_num = 1)
+  hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(256), 0, s, n, dim, fixed_axis, prob,
+                     static_cast<const float*>(nullptr),
+                     reinterpret_cast<unsigned long long*>(base + lay.keys0),
+                     reinterpret_cast<unsigned*>(base + lay.vals0));
+  int rc = sort_pairs(lay, base, ws_bytes, n, 32u, s);
+  if (rc != MMS_OK) return rc;
+  hipLaunchKernelGGL(auc_fold_kernel, dim3(1), dim3(64), 0, s, n,
+                     reinterpret_cast<unsigned*>(base + lay.vals1), label, has_ignore, ignore_label,
+                     auc_out);
+  return launch_status();
+}
+
+int rank_accuracy(int count, const float* a, const float* b, const float* label, float* out,
+                  void* ws, size_t ws_bytes, hipStream_t s) {
+  int blocks = (count + 1023) / 1024;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  if (!ws || ws_bytes < (size_t)blocks * sizeof(unsigned)) return MMS_ERR_WORKSPACE;
+  unsigned* partial = static_cast<unsigned*>(ws);
+  hipLaunchKernelGGL(rank_accuracy_kernel, dim3(blocks), dim3(256), 0, s, count, a, b, label, partial);
+  hipLaunchKernelGGL(rank_accuracy_finish_kernel, dim3(1), dim3(64), 0, s, blocks, count, partial, out);
+  return launch_status();
+}
+
+}  // namespace mms

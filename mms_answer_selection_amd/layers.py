@@ -226,3 +226,20 @@ def SimMatrix(**kw):
 
 def PairRankLoss(**kw):
     return _make("PairRankLoss", "pair_rank_loss_param", **kw)
+
+
+def MAP(**kw):
+    """L.MAP(prob, label, group)  (do_trec_qa_clean.py:495)."""
+    return _make("MAP", "map_param", **kw)
+
+
+def MRR(**kw):
+    return _make("MRR", "mrr_param", **kw)
+
+
+def AUC(**kw):
+    return _make("AUC", "auc_param", **kw)
+
+
+def RankAccuracy(**kw):
+    return _make("RankAccuracy", "rank_accuracy_param", **kw)

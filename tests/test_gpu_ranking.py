@@ -1,0 +1,126 @@
+"""GPU parity for the ranking metrics: MAP / MRR / AUC /
+RankAccuracy through the C ABI against the oracle's std::map + std::sort
+restatement -- bit-exact, because the sequential float walks are reproduced --
+and the end-to-end statement of BASELINE.json: ranking output computed from
+GPU scores is identical to the one computed from CPU scores."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import assert_bitexact, qa, rng
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def split(r, n, groups, pos_rate=0.17):
+    group = np.sort(r.integers(0, groups, n)).astype(np.float32)
+    label = (r.uniform(size=n) < pos_rate).astype(np.float32)
+    # DISTINCT scores: the reference's order among equal scores is implementation-defined
+    # (unstable std::sort), so bit-exactness is only defined without cross-label ties
+    score = ((r.permutation(n) + 0.5) / n).astype(np.float32)
+    assert np.unique(score).size == n
+    return group, label, score
+
+
+def same_bits(x, y):
+    return np.float32(x).view(np.uint32) == np.float32(y).view(np.uint32) or (np.isnan(x) and np.isnan(y))
+
+
+def test_golden_trec_split(oracle, hiplib):
+    from mms_answer_selection_amd import capi
+    g = dict(np.load(os.path.join(GOLD, "ranking_1517_68.npz")))
+    m, rr, eff = capi.rank_map_mrr(dev(g["prob"]), dev(g["label"]), dev(g["group"]))
+    assert same_bits(m, g["map"]) and same_bits(rr, g["mrr"]) and eff == int(g["effective"])
+    assert same_bits(capi.rank_auc(dev(g["prob"]), dev(g["label"])), g["auc"])
+
+
+@pytest.mark.parametrize("cfg", [(1517, 68), (1148, 65), (37, 5), (1, 1), (20000, 700)])
+def test_map_mrr_auc_random(cfg, oracle, hiplib):
+    from mms_answer_selection_amd import capi
+    n, groups = cfg
+    r = rng(n)
+    group, label, score = split(r, n, groups)
+    perm = r.permutation(n)                     # buckets arrive interleaved, as from a shuffled net
+    group, label, score = group[perm], label[perm], score[perm]
+    group -= 3                                   # negative group ids order like std::map<int>
+    prob = np.stack([1 - score, score], 1).astype(np.float32)
+    m_ref, eff_ref = oracle.map_score(prob, label, group)
+    rr_ref, _ = oracle.mrr_score(prob, label, group)
+    m, rr, eff = capi.rank_map_mrr(dev(prob), dev(label), dev(group))
+    assert eff == eff_ref
+    assert same_bits(m, m_ref), (m, m_ref)
+    assert same_bits(rr, rr_ref), (rr, rr_ref)
+    assert same_bits(capi.rank_auc(dev(prob), dev(label)), oracle.auc_score(prob, label))
+
+
+def test_skipped_buckets_and_empty_result(oracle, hiplib):
+    from mms_answer_selection_amd import capi
+    # all-positive and all-negative buckets are skipped (map_layer.cpp:90-92); nothing left -> NaN
+    group = np.array([0, 0, 1, 1, 1], np.float32)
+    label = np.array([1, 1, 0, 0, 0], np.float32)
+    prob = np.stack([np.zeros(5), np.linspace(0.1, 0.9, 5)], 1).astype(np.float32)
+    m, rr, eff = capi.rank_map_mrr(dev(prob), dev(label), dev(group))
+    assert eff == 0 and np.isnan(m) and np.isnan(rr)
+    m_ref, eff_ref = oracle.map_score(prob, label, group)
+    assert eff_ref == 0 and np.isnan(m_ref)
+    # AUC with no positive is 0 (auc_layer.cpp:127-134)
+    assert capi.rank_auc(dev(prob), dev(np.zeros(5, np.float32))) == 0.0
+
+
+def test_ties_with_equal_labels_are_order_independent(oracle, hiplib):
+    """Equal scores: the reference's order is implementation-defined (unstable sort);
+    when the tied items share a label every order gives the same metric."""
+    from mms_answer_selection_amd import capi
+    group = np.zeros(8, np.float32)
+    score = np.array([.9, .5, .5, .5, .3, .3, .1, .05], np.float32)
+    label = np.array([0, 1, 1, 1, 0, 0, 1, 0], np.float32)
+    prob = np.stack([1 - score, score], 1).astype(np.float32)
+    m, rr, _ = capi.rank_map_mrr(dev(prob), dev(label), dev(group))
+    m_ref, _ = oracle.map_score(prob, label, group)
+    rr_ref, _ = oracle.mrr_score(prob, label, group)
+    assert same_bits(m, m_ref) and same_bits(rr, rr_ref)
+
+
+def test_rank_accuracy(oracle, hiplib):
+    from mms_answer_selection_amd import capi
+    r = rng(11)
+    n = 5000
+    a = r.uniform(size=n).astype(np.float32)
+    b = r.uniform(size=n).astype(np.float32)
+    lab = r.choice([-1.0, 0.0, 1.0], n).astype(np.float32)
+    assert same_bits(capi.rank_accuracy(dev(a), dev(b), dev(lab)), oracle.rank_accuracy(a, b, lab))
+
+
+def test_end_to_end_ranking_identical_to_cpu(oracle, hiplib):
+    """cfg 4 in miniature: score a TREC-QA-sized split (1517 candidates, 68 questions,
+    sentence vectors) with the HIP SimCross, rank on the GPU, and compare with the CPU
+    pipeline (oracle scores -> oracle metrics): scores, argsort, MAP, MRR, AUC all identical."""
+    from mms_answer_selection_amd import capi
+    n, groups, D = 1517, 68, 300
+    r = rng(4)
+    group, label, _ = split(r, n, groups)
+    qvec = (r.standard_normal((groups, D)) * 0.4).astype(np.float32)
+    q = qvec[group.astype(int)].reshape(n, 1, D)
+    a = (q + r.standard_normal((n, 1, D)).astype(np.float32) * np.where(label, 0.2, 0.4).reshape(n, 1, 1)
+         ).astype(np.float32)
+    top_ref, _, _ = oracle.simcross_forward(1, q, a)
+    top = torch.empty(n, 1, 1, 1, device="cuda")
+    capi.simcross_forward(1, dev(q), dev(a), top)
+    s_gpu = top.view(n)
+    assert_bitexact(s_gpu.cpu().numpy(), top_ref.reshape(n), "scores")
+    assert (np.argsort(-s_gpu.cpu().numpy(), kind="stable") == np.argsort(-top_ref.reshape(n), kind="stable")).all()
+    prob_gpu = torch.stack([1 - s_gpu, s_gpu], 1).contiguous()
+    prob_ref = np.stack([1 - top_ref.reshape(n), top_ref.reshape(n)], 1).astype(np.float32)
+    m, rr, eff = capi.rank_map_mrr(prob_gpu, dev(label), dev(group))
+    m_ref, eff_ref = oracle.map_score(prob_ref, label, group)
+    rr_ref, _ = oracle.mrr_score(prob_ref, label, group)
+    assert eff == eff_ref and same_bits(m, m_ref) and same_bits(rr, rr_ref)
+    assert same_bits(capi.rank_auc(prob_gpu, dev(label)), oracle.auc_score(prob_ref, label))
+    assert m > 0.5          # the synthetic positives really are closer

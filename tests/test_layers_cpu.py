@@ -28,7 +28,8 @@ def test_header_symbols_exported(L):
 
 def test_registry_has_reference_type_strings(L):
     # sim_cross_layer.hpp:22, sim_matrix_layer.hpp:22, pair_rank_loss_layer.hpp:24
-    assert sorted(L.registered_layer_types()) == ["PairRankLoss", "SimCross", "SimMatrix"]
+    assert sorted(L.registered_layer_types()) == ["AUC", "MAP", "MRR", "PairRankLoss", "RankAccuracy",
+                                                  "SimCross", "SimMatrix"]
 
 
 def test_prototxt_as_written_by_the_driver(L):

@@ -171,6 +171,37 @@ def test_pairrank_layer(L, oracle):
     assert_bitexact(ba.diff, da2)
 
 
+def test_metric_layers_on_network_v4_outputs(L, oracle):
+    """MRR / MAP / AUC as the test net wires them: L.MRR(prob, label, group) etc.
+    (do_trec_qa_clean.py:494-496), prob = softmax output (N,2)."""
+    r = rng(6)
+    n, groups = 1517, 68
+    group = np.sort(r.integers(0, groups, n)).astype(np.float32)
+    label = (r.uniform(size=n) < 0.17).astype(np.float32)
+    score = ((r.permutation(n) + 0.5) / n).astype(np.float32)
+    prob = np.stack([1 - score, score], 1).astype(np.float32)
+    bp, bl, bg = blob(L, prob), blob(L, label), blob(L, group)
+    for make, ref in ((L.MAP, oracle.map_score(prob, label, group)[0]),
+                      (L.MRR, oracle.mrr_score(prob, label, group)[0])):
+        lay, top = make(), L.Blob((7,))
+        lay.SetUp([bp, bl, bg], [top])
+        assert top.shape == ()
+        lay.Forward([bp, bl, bg], [top])
+        assert np.float32(top.data.reshape(-1)[0]).view(np.uint32) == np.float32(ref).view(np.uint32)
+    lay, top = L.AUC(), L.Blob()
+    lay.SetUp([bp, bl], [top])
+    lay.Forward([bp, bl], [top])
+    assert top.data.reshape(-1)[0] == oracle.auc_score(prob, label)
+    a = r.uniform(size=(64, 1)).astype(np.float32)
+    b = r.uniform(size=(64, 1)).astype(np.float32)
+    y = r.choice([-1.0, 1.0], (64, 1)).astype(np.float32)
+    lay, top = L.Layer('layer { type: "RankAccuracy" }'), L.Blob()
+    ba, bb, by = blob(L, a), blob(L, b), blob(L, y)
+    lay.SetUp([ba, bb, by], [top])
+    lay.Forward([ba, bb, by], [top])
+    assert top.data.reshape(-1)[0] == oracle.rank_accuracy(a, b, y)
+
+
 def _run_snippet(code):
     return subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\n%s" % (ROOT, code)],
                           capture_output=True, text=True, timeout=300)
