@@ -36,6 +36,7 @@ struct GemmArgs {
   long long a_b0, a_b1, b_b0, b_b1, c_b0, c_b1, c_ks;
   const float* rowscale; long long rs_b0;  // optional C(i,j) = rowscale[i] * acc
   const float* addend; long long ad_b1;    // optional C(i,j) += addend[i*ldc + j]
+  const float* bkscale;                    // optional B(k,j) *= bkscale[k] on load (fast j-vector path)
   int beta_one;                            // C = result + C
   int a_ifast, b_jfast;                    // which index is contiguous in memory
 };
@@ -143,6 +144,164 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
   }
 }
 
+// ---- fast path: 64x64x16 tiles, 16-byte global loads, permuted-k fragments --
+// Eligible when each operand is contiguous in one direction with 16-byte
+// alignment (A along k or along i, B along j or along k) -- true for every
+// large GEMM of this file at D = 300 / 1024.  Differences from the generic
+// kernel above:
+//   * FK/16 float4 global loads per operand per thread per k-tile, issued for the
+//     NEXT tile before the MFMAs of the current one; pointers are bumped, no
+//     64-bit multiplies in the loop;
+//   * A lives in LDS as [i][k] (k contiguous, row stride 20 floats).  A
+//     32x32x2 MFMA consumes two k values per instruction and the pairing is
+//     free as long as A and B agree, so instruction t of a tile uses
+//     k = t (lanes 0-31) and k = t + FK/2 (lanes 32-63): every lane's FK/2 A
+//     values are then CONTIGUOUS -- FK/8 ds_read_b128, conflict-free at stride
+//     FK+4 (20 or 36 floats) -- instead of FK/2 ds_read_b32;
+//   * 4 waves as 2 x 2, each one 32x32 accumulator: at M = 16384, N = 300 the
+//     grid is 256 x 5 = 1280 workgroups = exactly 5 per CU (no tail).
+// FK = 16 measured faster than 32 at cfg 3 (43 vs 67 us for the 16384x300x300 product):
+// the shallower tile keeps more workgroups' loads in flight per CU.
+constexpr int FM = 64, FN = 64, FK = 16, LSK = FK + 4, LSJ = FN + 4;
+constexpr int FSL = FK / 16;     // float4 load slots per operand per thread per tile
+constexpr int FH = FK / 2;       // k values per half-wave per tile
+
+template <bool A_KVEC, bool B_JVEC, bool KSCALE>
+__global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
+  __shared__ float As[FM * LSK];
+  __shared__ float Bs[FK * LSJ];
+  const int z = blockIdx.z;
+  const int ks = z % g.ksplit;
+  const int b1 = (z / g.ksplit) % g.nb1;
+  const int b0 = (z / g.ksplit) / g.nb1;
+  const float* A = g.A + b0 * g.a_b0 + b1 * g.a_b1;
+  const float* B = g.B + b0 * g.b_b0 + b1 * g.b_b1;
+  float* C = g.C + b0 * g.c_b0 + b1 * g.c_b1 + ks * g.c_ks;
+  const int kbeg = ks * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int i0 = blockIdx.y * FM, j0 = blockIdx.x * FN;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+
+  // this thread's load slots: FSL float4 per operand per tile
+  int ai[FSL], ak[FSL], bj[FSL], bk[FSL];  // tile-local coordinates
+#pragma unroll
+  for (int sl = 0; sl < FSL; ++sl) {
+    const int u = t + 256 * sl;
+    if (A_KVEC) { ai[sl] = u / (FK / 4); ak[sl] = (u % (FK / 4)) * 4; } else { ak[sl] = u >> 4; ai[sl] = (u & 15) * 4; }
+    if (B_JVEC) { bk[sl] = u >> 4; bj[sl] = (u & 15) * 4; } else { bj[sl] = u / (FK / 4); bk[sl] = (u % (FK / 4)) * 4; }
+  }
+  const float* pa[FSL];
+  const float* pb[FSL];
+  bool a_ok[FSL], b_ok[FSL];
+#pragma unroll
+  for (int sl = 0; sl < FSL; ++sl) {
+    a_ok[sl] = i0 + ai[sl] < g.M;              // M % 4 == 0 on the i-vector path
+    b_ok[sl] = j0 + bj[sl] < g.N;              // N % 4 == 0 on the j-vector path
+    pa[sl] = A + (long long)(i0 + ai[sl]) * g.a_rs + (long long)(kbeg + ak[sl]) * g.a_cs;
+    pb[sl] = B + (long long)(kbeg + bk[sl]) * g.b_rs + (long long)(j0 + bj[sl]) * g.b_cs;
+  }
+  const long long a_step = (long long)FK * g.a_cs, b_step = (long long)FK * g.b_rs;
+  const float* ksc = g.bkscale;
+
+  float4 ra[FSL], rb[FSL];
+  float sc[FSL];
+#pragma unroll
+  for (int sl = 0; sl < FSL; ++sl) sc[sl] = 1.f;
+  auto load = [&](int k0) {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int sl = 0; sl < FSL; ++sl) {
+      ra[sl] = (a_ok[sl] && k0 + ak[sl] < kend) ? *reinterpret_cast<const float4*>(pa[sl]) : z4;
+      const bool bv = b_ok[sl] && k0 + bk[sl] < kend;
+      rb[sl] = bv ? *reinterpret_cast<const float4*>(pb[sl]) : z4;
+      // the scale is only FETCHED here (clamped index, no dependent use): multiplying now
+      // would put a vmcnt(0) wait in front of the MFMAs and drain the prefetch
+      if (KSCALE) sc[sl] = ksc[min(k0 + bk[sl], g.K - 1)];
+      pa[sl] += a_step;
+      pb[sl] += b_step;
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int sl = 0; sl < FSL; ++sl) {
+      if (A_KVEC) {
+        *reinterpret_cast<float4*>(&As[ai[sl] * LSK + ak[sl]]) = ra[sl];
+      } else {
+        As[(ai[sl] + 0) * LSK + ak[sl]] = ra[sl].x; As[(ai[sl] + 1) * LSK + ak[sl]] = ra[sl].y;
+        As[(ai[sl] + 2) * LSK + ak[sl]] = ra[sl].z; As[(ai[sl] + 3) * LSK + ak[sl]] = ra[sl].w;
+      }
+      if (B_JVEC) {
+        float4 v = rb[sl];
+        if (KSCALE) { v.x *= sc[sl]; v.y *= sc[sl]; v.z *= sc[sl]; v.w *= sc[sl]; }
+        *reinterpret_cast<float4*>(&Bs[bk[sl] * LSJ + bj[sl]]) = v;
+      } else {
+        Bs[(bk[sl] + 0) * LSJ + bj[sl]] = rb[sl].x; Bs[(bk[sl] + 1) * LSJ + bj[sl]] = rb[sl].y;
+        Bs[(bk[sl] + 2) * LSJ + bj[sl]] = rb[sl].z; Bs[(bk[sl] + 3) * LSJ + bj[sl]] = rb[sl].w;
+      }
+    }
+  };
+
+  v16f acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+
+  if (kbeg < kend) {
+    load(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += FK) {
+      __syncthreads();
+      store();
+      __syncthreads();
+      if (k0 + FK < kend) load(k0 + FK);
+      const float4* arow = reinterpret_cast<const float4*>(&As[(wm * 32 + r) * LSK + FH * h]);
+      float av[FH], bv[FH];
+#pragma unroll
+      for (int u4 = 0; u4 < FH / 4; ++u4) {
+        const float4 v = arow[u4];
+        av[4 * u4] = v.x; av[4 * u4 + 1] = v.y; av[4 * u4 + 2] = v.z; av[4 * u4 + 3] = v.w;
+      }
+#pragma unroll
+      for (int u = 0; u < FH; ++u) bv[u] = Bs[(u + FH * h) * LSJ + wn * 32 + r];
+#pragma unroll
+      for (int u = 0; u < FH; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+  }
+
+  const float* rs = g.rowscale ? g.rowscale + b0 * g.rs_b0 : nullptr;
+  const float* ad = g.addend ? g.addend + b1 * g.ad_b1 : nullptr;
+  const int gj = j0 + wn * 32 + r;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int gi = i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    if (gi >= g.M || gj >= g.N) continue;
+    float v = acc[q];
+    if (rs) v = rs[gi] * v;
+    if (ad) v = ad[gi * g.ldc + gj] + v;
+    float* c = C + gi * g.ldc + gj;
+    if (g.beta_one) v = v + *c;
+    *c = v;
+  }
+}
+
+static bool mult4(long long x) { return (x & 3) == 0; }
+// which fast variant (if any) can run these arguments: 0 none, else 1 + 2*A_KVEC + B_JVEC
+static int gemm_fast_variant(const GemmArgs& g) {
+  if (g.kchunk % FK != 0 && g.ksplit > 1) return 0;
+  if (g.bkscale && !(g.b_cs == 1)) return 0;
+  const bool bases = aligned16(g.A) && aligned16(g.B) && mult4(g.a_b0) && mult4(g.a_b1) &&
+                     mult4(g.b_b0) && mult4(g.b_b1);
+  if (!bases || !mult4(g.K)) return 0;
+  int a_kvec;
+  if (g.a_cs == 1 && mult4(g.a_rs)) a_kvec = 1;
+  else if (g.a_rs == 1 && mult4(g.a_cs) && mult4(g.M)) a_kvec = 0;
+  else return 0;
+  int b_jvec;
+  if (g.b_cs == 1 && mult4(g.b_rs) && mult4(g.N)) b_jvec = 1;
+  else if (g.b_rs == 1 && mult4(g.b_cs)) b_jvec = 0;
+  else return 0;
+  return 1 + 2 * a_kvec + b_jvec;
+}
+
 static GemmArgs gemm_args(int M, int N, int K, const float* A, long long a_rs, long long a_cs,
                           const float* B, long long b_rs, long long b_cs, float* C,
                           long long ldc) {
@@ -168,6 +327,24 @@ static void gemm_launch(const GemmArgs& g0, int nb0, hipStream_t s) {
     g.B += (long long)b * g.b_b0;
     g.C += (long long)b * g.c_b0;
     if (g.rowscale) g.rowscale += (long long)b * g.rs_b0;
+    const int fv = gemm_fast_variant(g);
+    if (fv) {
+      dim3 grid((g.N + FN - 1) / FN, (g.M + FM - 1) / FM, nb * per_b0);
+      const bool ksc = g.bkscale != nullptr;   // only with B_JVEC (gemm_fast_variant)
+      switch (fv - 1) {
+        case 0: hipLaunchKernelGGL((gemm32_fast_kernel<false, false, false>), grid, dim3(256), 0, s, g); break;
+        case 1:
+          if (ksc) hipLaunchKernelGGL((gemm32_fast_kernel<false, true, true>), grid, dim3(256), 0, s, g);
+          else hipLaunchKernelGGL((gemm32_fast_kernel<false, true, false>), grid, dim3(256), 0, s, g);
+          break;
+        case 2: hipLaunchKernelGGL((gemm32_fast_kernel<true, false, false>), grid, dim3(256), 0, s, g); break;
+        default:
+          if (ksc) hipLaunchKernelGGL((gemm32_fast_kernel<true, true, true>), grid, dim3(256), 0, s, g);
+          else hipLaunchKernelGGL((gemm32_fast_kernel<true, true, false>), grid, dim3(256), 0, s, g);
+          break;
+      }
+      continue;
+    }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, nb * per_b0);
     hipLaunchKernelGGL(gemm32_kernel, grid, dim3(256), 0, s, g);
   }
@@ -234,14 +411,14 @@ static unsigned ew_blocks(long long n) {
 }
 
 static int pick_ksplit(int Mt, int Nt, int K, int* kchunk) {
-  const long long tiles = (long long)((Mt + BM - 1) / BM) * ((Nt + BN - 1) / BN);
-  long long want = (1024 + tiles - 1) / tiles;  // aim for ~4 workgroups per CU
-  long long maxs = (K + 4 * BK - 1) / (4 * BK); // at least 64 of K per split
+  const long long tiles = (long long)((Mt + FM - 1) / FM) * ((Nt + FN - 1) / FN);
+  long long want = (768 + tiles - 1) / tiles;   // aim for ~3 workgroups per CU
+  long long maxs = (K + 255) / 256;             // at least 256 of K per split
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   if (want > 256) want = 256;
   int chunk = (int)((K + want - 1) / want);
-  chunk = (chunk + BK - 1) / BK * BK;
+  chunk = (chunk + FK - 1) / FK * FK;
   *kchunk = chunk;
   return (K + chunk - 1) / chunk;
 }
@@ -393,10 +570,15 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
     float* U = reinterpret_cast<float*>(base + lay.u_off);
     float* part = reinterpret_cast<float*>(base + lay.part_off);
     // dW += sum_i dT_i q_i a_i^T = Q^T (diag(dT) A)   (:73-80, accumulating)
-    hipLaunchKernelGGL(rowscale_kernel, dim3(ew_blocks((long long)N * K2)), dim3(256), 0, s, a,
-                       top_diff, U, (long long)N, K2);
-    GemmArgs g = gemm_args(K1, K2, N, q, 1, K1, U, K2, 1, part, K2);
+    GemmArgs g = gemm_args(K1, K2, N, q, 1, K1, a, K2, 1, part, K2);
     g.ksplit = lay.ksplit; g.kchunk = lay.kchunk; g.c_ks = (long long)K1 * K2;
+    g.bkscale = top_diff;                       // B(k = pair, j) = dT_k * a_k[j], scaled on load
+    if (!gemm_fast_variant(g)) {                // generic kernel: materialise U = diag(dT) A first
+      hipLaunchKernelGGL(rowscale_kernel, dim3(ew_blocks((long long)N * K2)), dim3(256), 0, s, a,
+                         top_diff, U, (long long)N, K2);
+      g.B = U;
+      g.bkscale = nullptr;
+    }
     gemm_launch(g, 1, s);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks((long long)K1 * K2)), dim3(256), 0, s,
                        part, lay.ksplit, (long long)K1 * K2, dW, 1);
