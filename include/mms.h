@@ -98,6 +98,19 @@ int mms_simcross_forward_backward_f32(int dist_mode, int N, int W1, int W2,
                                       float* dbias, void* workspace,
                                       size_t workspace_bytes, void* stream);
 
+/* fp16-STORAGE variants of the Euclidean sentence-vector path (W1 = W2 = 1,
+ * dist_mode 1; BASELINE cfg 5): q, a, dq, da are IEEE half in HBM, the scores
+ * and top_diff stay fp32, and all arithmetic is the fp32 reference arithmetic on
+ * the exactly-widened inputs -- top equals the fp32 result on those inputs bit
+ * for bit and dq/da are its correctly rounded (RNE) halves.  D % 8 == 0,
+ * D <= 2048.  The reference has no fp16 instantiation (common.hpp:41-44). */
+int mms_simcross_euclid_forward_f16(int N, int D, const void* q_f16, const void* a_f16,
+                                    float* top, void* stream);
+int mms_simcross_euclid_forward_backward_f16(int N, int D, const void* q_f16,
+                                             const void* a_f16, const float* top_diff,
+                                             float* top, void* dq_f16, void* da_f16,
+                                             void* stream);
+
 /* Device scratch needed by the three calls above (0 is possible). */
 size_t mms_simcross_workspace_bytes(int dist_mode, int N, int W1, int W2, int D,
                                     int M);

@@ -32,6 +32,8 @@ _SIGNATURES = {
     "mms_pairrank_backward_f32": (_i, [_i, _f] + [_vp] * 3 + [_i, _i] + [_vp] * 3),
     "mms_triplet_workspace_bytes": (_sz, [_i]),
     "mms_triplet_euclid_step_f32": (_i, [_i, _i, _f, _f] + [_vp] * 11 + [_sz, _vp]),
+    "mms_simcross_euclid_forward_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "mms_simcross_euclid_forward_backward_f16": (_i, [_i, _i] + [_vp] * 7),
     "mms_rank_workspace_bytes": (_sz, [_i]),
     "mms_rank_map_mrr_f32": (_i, [_i, _i] + [_vp] * 7 + [_sz, _vp]),
     "mms_rank_auc_f32": (_i, [_i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
@@ -67,7 +69,7 @@ def check(rc, what):
         raise MMSError("%s failed: %s (code %d)" % (what, lib().mms_error_string(rc).decode(), rc))
 
 
-def _ptr(t, name, allow_none=False):
+def _ptr(t, name, allow_none=False, dtype=torch.float32):
     if t is None:
         if allow_none:
             return None
@@ -75,8 +77,8 @@ def _ptr(t, name, allow_none=False):
     if not t.is_cuda:
         raise MMSError("%s must live in GPU memory (got %s); the HIP path has no CPU fallback"
                        % (name, t.device))
-    if t.dtype != torch.float32:
-        raise MMSError("%s must be float32 (got %s)" % (name, t.dtype))
+    if t.dtype != dtype:
+        raise MMSError("%s must be %s (got %s)" % (name, dtype, t.dtype))
     if not t.is_contiguous():
         raise MMSError("%s must be contiguous" % name)
     return t.data_ptr()
@@ -224,3 +226,21 @@ def rank_accuracy(a, b, label, ws=None):
     check(lib().mms_rank_accuracy_f32(n, _ptr(a, "a"), _ptr(b, "b"), _ptr(label, "label"),
                                       out.data_ptr(), wsp, wsb, _stream()), "mms_rank_accuracy_f32")
     return out.cpu().numpy()[0]
+
+
+def simcross_euclid_forward_f16(q, a, top):
+    """fp16-storage scoring (cfg 5): q, a half tensors (N,1,D); top float32."""
+    N, D = q.shape[0], q.shape[-1]
+    h = torch.float16
+    check(lib().mms_simcross_euclid_forward_f16(N, D, _ptr(q, "q", dtype=h), _ptr(a, "a", dtype=h),
+                                                _ptr(top, "top"), _stream()),
+          "mms_simcross_euclid_forward_f16")
+
+
+def simcross_euclid_forward_backward_f16(q, a, top_diff, top, dq, da):
+    N, D = q.shape[0], q.shape[-1]
+    h = torch.float16
+    check(lib().mms_simcross_euclid_forward_backward_f16(
+        N, D, _ptr(q, "q", dtype=h), _ptr(a, "a", dtype=h), _ptr(top_diff, "top_diff"),
+        _ptr(top, "top"), _ptr(dq, "dq", dtype=h), _ptr(da, "da", dtype=h), _stream()),
+        "mms_simcross_euclid_forward_backward_f16")

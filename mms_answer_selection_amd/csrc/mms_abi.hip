@@ -15,6 +15,8 @@ int simcross_elementwise_forward_backward(int mode, int N, int W1, int W2, int D
                                           const float* a, const float* top_diff, float* top,
                                           float* norm0, float* norm1, float* dq, float* da,
                                           hipStream_t s);
+int simcross_euclid_rows_f16(int N, int D, const void* q, const void* a, const float* top_diff,
+                             float* top, void* dq, void* da, bool bwd, hipStream_t s);
 // bilinear.hip
 size_t bilinear_workspace_bytes(int N, int W1, int W2, int D, int M);
 int bilinear_forward(int N, int W1, int W2, int D, int M, const float* q, const float* a,
@@ -153,6 +155,25 @@ int mms_simcross_forward_backward_f32(int dist_mode, int N, int W1, int W2, int 
   }
   return simcross_elementwise_forward_backward(dist_mode, N, W1, W2, D, q, a, top_diff, top, norm0,
                                                norm1, dq, da, as_stream(stream));
+}
+
+int mms_simcross_euclid_forward_f16(int N, int D, const void* q_f16, const void* a_f16, float* top,
+                                    void* stream) {
+  if (N < 0 || D <= 0 || (long long)N * D > 0x7fffffffLL) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q_f16 || !a_f16 || !top) return MMS_ERR_INVALID_ARG;
+  return simcross_euclid_rows_f16(N, D, q_f16, a_f16, nullptr, top, nullptr, nullptr, false,
+                                  as_stream(stream));
+}
+
+int mms_simcross_euclid_forward_backward_f16(int N, int D, const void* q_f16, const void* a_f16,
+                                             const float* top_diff, float* top, void* dq_f16,
+                                             void* da_f16, void* stream) {
+  if (N < 0 || D <= 0 || (long long)N * D > 0x7fffffffLL) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q_f16 || !a_f16 || !top_diff || !top || !dq_f16 || !da_f16) return MMS_ERR_INVALID_ARG;
+  return simcross_euclid_rows_f16(N, D, q_f16, a_f16, top_diff, top, dq_f16, da_f16, true,
+                                  as_stream(stream));
 }
 
 size_t mms_simmatrix_workspace_bytes(int N, int K1, int K2) {

@@ -154,6 +154,126 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
   }
 }
 
+// ---- fp16 storage, fp32 arithmetic (BASELINE cfg 5) --------------------------
+// Same wave-centric structure with one pair per wave (cfg 5 is D = 1024): q, a,
+// dq, da live in HBM as IEEE half (half the bytes per pair: s = 2 in SURVEY
+// 8d's formulas); every half is widened exactly to fp32 on load, ALL arithmetic
+// is the fp32 reference arithmetic in the reference order, and only the final
+// dq / da are rounded (RNE) to half.  The scores stay fp32.  Hence:
+//   top == oracle(fp32(q_half), fp32(a_half)) bit for bit, and
+//   dq  == half(oracle dq) bit for bit.
+// The reference has no fp16 instantiation (common.hpp:41-44); this is an
+// MI355X-side storage format, not a change of the layer's numerics.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+template <int NIT, bool BWD>
+__global__ __launch_bounds__(256) void euclid_rows_wave_f16_kernel(
+    const _Float16* __restrict__ q, const _Float16* __restrict__ a,
+    const float* __restrict__ top_diff, float* __restrict__ top_out,
+    _Float16* __restrict__ dq, _Float16* __restrict__ da, int N, int D8) {
+  constexpr int LPR = 64;
+  extern __shared__ float4 lds4[];               // [4 waves] one image each (euclid_math.h)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= N) return;
+  const int D4 = 2 * D8;
+  const size_t base8 = (size_t)row * D8;
+  const half8* q8 = reinterpret_cast<const half8*>(q) + base8;
+  const half8* a8 = reinterpret_cast<const half8*>(a) + base8;
+  const int st4 = spec_stride4(D4), h4 = spec_h4(D4);
+  float4* sq4 = lds4 + (size_t)wave * st4;
+
+  half8 x[NIT], y[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane + 64 * it;
+    const int ii = i < D8 ? i : 0;
+    x[it] = q8[ii];
+    y[it] = a8[ii];
+  }
+  float g = 0.f;
+  if (BWD) g = top_diff[row];
+
+  float4 df[2 * NIT];
+  float pred1 = 0.f, pred2 = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane + 64 * it;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      float4 d;
+      d.x = (float)x[it][4 * hh + 0] - (float)y[it][4 * hh + 0];
+      d.y = (float)x[it][4 * hh + 1] - (float)y[it][4 * hh + 1];
+      d.z = (float)x[it][4 * hh + 2] - (float)y[it][4 * hh + 2];
+      d.w = (float)x[it][4 * hh + 3] - (float)y[it][4 * hh + 3];
+      df[2 * it + hh] = d;
+      float4 s;
+      s.x = d.x * d.x; s.y = d.y * d.y; s.z = d.z * d.z; s.w = d.w * d.w;
+      const int i4 = 2 * i + hh;
+      if (i < D8) sq4[i4] = s;
+      const float s4 = (i < D8) ? (s.x + s.y) + (s.z + s.w) : 0.f;
+      pred1 += (i4 < h4) ? s4 : 0.f;
+      pred2 += (i4 < 2 * h4) ? s4 : 0.f;
+    }
+  }
+  const int npad = st4 - D4;
+  if (lane < npad) sq4[D4 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+  pred1 = wave_sum(pred1);
+  pred2 = wave_sum(pred2);
+  wave_lds_sync();
+  const float dist = chain_sum_speculative<LPR>(sq4, D4, pred1, pred2, lane, 0);
+  const float T = 1.0f / (1.0f + sqrtf(dist));
+  if (lane == 0) top_out[row] = T;
+  if (!BWD) return;
+
+  const EuclidCoef k = euclid_coef(T, g);
+  half8* dq8 = reinterpret_cast<half8*>(dq) + base8;
+  half8* da8 = reinterpret_cast<half8*>(da) + base8;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane + 64 * it;
+    if (i >= D8) break;
+    half8 o0, o1;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const float4 t = euclid_tt4(k, df[2 * it + hh]);
+      o0[4 * hh + 0] = (_Float16)(0.f + t.x); o0[4 * hh + 1] = (_Float16)(0.f + t.y);
+      o0[4 * hh + 2] = (_Float16)(0.f + t.z); o0[4 * hh + 3] = (_Float16)(0.f + t.w);
+      o1[4 * hh + 0] = (_Float16)(0.f + (-t.x)); o1[4 * hh + 1] = (_Float16)(0.f + (-t.y));
+      o1[4 * hh + 2] = (_Float16)(0.f + (-t.z)); o1[4 * hh + 3] = (_Float16)(0.f + (-t.w));
+    }
+    dq8[i] = o0;
+    da8[i] = o1;
+  }
+}
+
+int simcross_euclid_rows_f16(int N, int D, const void* q, const void* a, const float* top_diff,
+                             float* top, void* dq, void* da, bool bwd, hipStream_t s) {
+  if (N == 0) return MMS_OK;
+  if (D % 8 != 0 || D > 2048 || !aligned16(q) || !aligned16(a) || (bwd && (!aligned16(dq) || !aligned16(da))))
+    return MMS_ERR_UNSUPPORTED;
+  const int D8 = D / 8;
+  const int nit = (D8 + 63) / 64;
+  const unsigned grid = (unsigned)((N + 3) / 4);
+  const size_t lds = (size_t)4 * 3 * ((2 * D8 + 2) / 3) * sizeof(float4);
+  const _Float16* qh = static_cast<const _Float16*>(q);
+  const _Float16* ah = static_cast<const _Float16*>(a);
+  _Float16* dqh = static_cast<_Float16*>(dq);
+  _Float16* dah = static_cast<_Float16*>(da);
+#define MMS_F16_CASE(n)                                                                          \
+  case n:                                                                                        \
+    if (bwd)                                                                                     \
+      hipLaunchKernelGGL((euclid_rows_wave_f16_kernel<n, true>), dim3(grid), dim3(256), lds, s,  \
+                         qh, ah, top_diff, top, dqh, dah, N, D8);                                \
+    else                                                                                         \
+      hipLaunchKernelGGL((euclid_rows_wave_f16_kernel<n, false>), dim3(grid), dim3(256), lds, s, \
+                         qh, ah, top_diff, top, dqh, dah, N, D8);                                \
+    break;
+  switch (nit) { MMS_F16_CASE(1) MMS_F16_CASE(2) MMS_F16_CASE(3) MMS_F16_CASE(4) }
+#undef MMS_F16_CASE
+  return launch_status();
+}
+
 // ---- generic fallback (any D, any alignment): workgroup of ROWS pairs --------
 // Forward (BWD=false) or forward+backward (BWD=true) for W1=W2=1, Euclidean.
 // LDS: diff[ROWS*D] floats (dynamic) + per-row coefficient slots.

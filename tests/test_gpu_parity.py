@@ -48,6 +48,7 @@ EUCLID_SHAPES = [
     (9, 1, 1, 404),      # first D with one pair per wave
     (3, 1, 1, 1028),     # beyond the wave kernel: generic rows kernel
     (1, 70, 60, 9),      # W1*W2 tables exceed LDS: generic cross backward
+    (2, 1, 1, 2100),     # rows wider than every rows kernel: cross kernels with W = 1
 ]
 
 
@@ -145,6 +146,35 @@ def test_euclid_subnormal_squares(oracle, hiplib):
     assert_bitexact(host(top), top_ref, "top")
     assert_bitexact(host(gq), dq_ref, "dq")
     assert_bitexact(host(ga), da_ref, "da")
+
+
+@pytest.mark.parametrize("cfg", [(8192, 1024), (33, 1024), (5, 8), (17, 2048), (9, 304)])
+def test_euclid_fp16_storage(cfg, oracle, hiplib):
+    """BASELINE cfg 5: half in HBM, fp32 reference arithmetic.  Against the fp32 oracle run on
+    the widened inputs: scores bit-exact, gradients equal to the oracle's rounded to half."""
+    from mms_answer_selection_amd import capi
+    N, D = cfg
+    r = rng(N + D)
+    qf, af = qa(r, N, 1, 1, D)
+    qh, ah = qf.astype(np.float16), af.astype(np.float16)
+    if N > 4:
+        ah[1] = qh[1]
+    dT = r.standard_normal((N, 1, 1, 1)).astype(np.float32)
+    q32, a32 = qh.astype(np.float32), ah.astype(np.float32)
+    top_ref, _, _ = oracle.simcross_forward(1, q32, a32)
+    dq_ref, da_ref, _, _ = oracle.simcross_backward(1, q32, a32, top_ref, dT)
+    qd = torch.from_numpy(qh).cuda()
+    ad = torch.from_numpy(ah).cuda()
+    top = nan_like(top_ref.shape)
+    capi.simcross_euclid_forward_f16(qd, ad, top)
+    assert_bitexact(host(top), top_ref, "top (forward only)")
+    top2 = nan_like(top_ref.shape)
+    gq = torch.full(qh.shape, float("nan"), dtype=torch.float16, device="cuda")
+    ga = torch.full(qh.shape, float("nan"), dtype=torch.float16, device="cuda")
+    capi.simcross_euclid_forward_backward_f16(qd, ad, dev(dT), top2, gq, ga)
+    assert_bitexact(host(top2), top_ref, "top")
+    assert (host(gq).view(np.uint16) == dq_ref.astype(np.float16).view(np.uint16)).all(), "dq halves"
+    assert (host(ga).view(np.uint16) == da_ref.astype(np.float16).view(np.uint16)).all(), "da halves"
 
 
 def test_euclid_unaligned_views_take_scalar_path(oracle, hiplib):

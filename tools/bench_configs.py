@@ -78,12 +78,31 @@ def simmatrix(N, K1, K2, iters=20):
                       "pairs_per_s_fwd_bwd": N / ((tf + tb) * 1e-6)}), flush=True)
 
 
+def simcross_f16(N, D, iters=20):
+    """BASELINE cfg 5 per-GPU shard: fp16 storage, fused fwd+bwd, one launch."""
+    q = rnd(N, 1, D).half()
+    a = rnd(N, 1, D).half()
+    dT = rnd(N, 1, 1, 1, scale=1.0)
+    top = torch.empty(N, 1, 1, 1, device=dev)
+    dq, da = torch.empty_like(q), torch.empty_like(a)
+    t = timeit(lambda: capi.simcross_euclid_forward_backward_f16(q, a, dT, top, dq, da), iters)
+    b_unfused = 2 * (3 * N * 2 * D) + 4 * 3 * N          # SURVEY 8d cfg 5 formula (s = 2)
+    b_fused = 2 * (2 * N * 2 * D) + 4 * 2 * N
+    print(json.dumps({"op": "SimCross Euclid fp16 storage fused fwd+bwd", "N": N, "D": D, "us": t,
+                      "pairs_per_s": N / (t * 1e-6), "GBps_alg_unfused": b_unfused / t / 1e3,
+                      "GBps_fused_bytes": b_fused / t / 1e3,
+                      "frac_hbm_unfused_bytes": b_unfused / (t * 1e-6) / 8e12}), flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "cross", "cfg3", "v4"]
     if "g1" in which:
         simcross(1, 4096, 1, 1, 300)
         simcross(0, 4096, 1, 1, 300)
         simcross(1, 65536, 1, 1, 1024, iters=10)      # cfg 5 shape (fp32 here)
+    if "cfg5" in which or "g1" in which:
+        simcross_f16(8192, 1024)                      # cfg 5: 65536 pairs over 8 GPUs
+        simcross_f16(65536, 1024, iters=10)
     if "cross" in which:
         simcross(1, 50, 40, 40, 50)                    # reference default geometry
         simcross(1, 32, 40, 40, 300)                   # cfg 1 geometry
