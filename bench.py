@@ -353,7 +353,74 @@ def variants(torch, capi, args):
             res[name]["frac_hbm_unfused_bytes"] = B_UNFUSED / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
         del bt, graphs
         torch.cuda.empty_cache()
+    res.update(other_configs(torch, capi))
     return res
+
+
+def _graph_time(torch, fn, iters=16, reps=6):
+    """Median us per call of `fn`, replayed from a hipGraph of `iters` calls (cache-warm)."""
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph, stream=cap):
+            for _ in range(iters):
+                fn()
+    torch.cuda.current_stream().wait_stream(cap)
+    gph.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / iters)
+    return sorted(ts)[len(ts) // 2]
+
+
+def other_configs(torch, capi):
+    """The other single-GPU BASELINE configs, measured next to the headline (cache-warm,
+    hipGraph-replayed): cfg 3 (SimMatrix on fp32 MFMA) and cfg 5's per-GPU shard (fp16 storage)."""
+    out = {}
+    g = torch.Generator(device="cuda").manual_seed(1701)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g) * 0.4
+    # cfg 3: SimMatrix q,a (16384,300), W (300,300) fp32
+    N, K = 16384, 300
+    q, a = rnd(N, K), rnd(N, K)
+    W = torch.rand(K, K, device="cuda", generator=g) * 0.16 - 0.08
+    dT = torch.randn(N, 1, device="cuda", generator=g)
+    top, scr = torch.empty(N, 1, device="cuda"), torch.empty(N, K, device="cuda")
+    dq, da, dW = torch.empty_like(q), torch.empty_like(a), torch.zeros_like(W)
+    ws = capi.Workspace()
+
+    def cfg3():
+        capi.simmatrix_forward(q, a, W, top, scr)
+        capi.simmatrix_backward(q, a, W, dT, dq, da, dW, ws=ws)
+    us = _graph_time(torch, cfg3, iters=4)
+    flops = 2.0 * N * K * K + 2.0 * N * K + 6.0 * N * K * K        # SURVEY 8(d)
+    out["cfg3_simmatrix_16384x300x300_fwd_bwd"] = {
+        "us_per_step": us, "pairs_per_s": N / (us * 1e-6), "TFLOPs": flops / us / 1e6,
+        "frac_mfma_fp32_peak": flops / (us * 1e-6) / 157.3e12, "bound": "mfma", "dtype": "f32"}
+    del q, a, W, dT, top, scr, dq, da, dW
+    # cfg 5 shard: 8192 pairs x 1024-d, fp16 storage, fused fwd+bwd (one launch)
+    N, D = 8192, 1024
+    qh, ah = rnd(N, 1, D).half(), rnd(N, 1, D).half()
+    dT = torch.randn(N, 1, 1, 1, device="cuda", generator=g)
+    top = torch.empty(N, 1, 1, 1, device="cuda")
+    dqh, dah = torch.empty_like(qh), torch.empty_like(ah)
+    us = _graph_time(torch, lambda: capi.simcross_euclid_forward_backward_f16(qh, ah, dT, top, dqh, dah))
+    b_unfused = 2 * (3 * N * 2 * D) + 4 * 3 * N                      # SURVEY 8(d), s = 2: 100.7 MB
+    out["cfg5_shard_8192x1024_fp16_storage_fused"] = {
+        "us_per_step": us, "pairs_per_s": N / (us * 1e-6),
+        "frac_hbm_unfused_bytes": b_unfused / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": "hbm",
+        "dtype": "f16 storage / f32 arithmetic"}
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":
