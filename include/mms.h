@@ -220,6 +220,29 @@ int mms_rank_accuracy_f32(int count, const float* a, const float* b, const float
 
 size_t mms_rank_workspace_bytes(int n);
 
+/* ------------------------------------------------------------------------- *
+ * Embed -- the layer that produces SimCross's bottoms.
+ * index (M) holds word ids as floats (Caffe feeds them as Dtype), weight (K,N),
+ * bias (N) or NULL, top (M,N).
+ * ------------------------------------------------------------------------- */
+
+/* Replaces EmbedLayer<float>::Forward_cpu / Forward_gpu
+ *   src/caffe/layers/embed_layer.cpp:135-152, embed_layer.cu:42-62. */
+int mms_embed_forward_f32(int M, int N, int K, const float* index, const float* weight,
+                          const float* bias, float* top, void* stream);
+
+/* Replaces EmbedLayer<float>::Backward_cpu / Backward_gpu
+ *   src/caffe/layers/embed_layer.cpp:155-180, embed_layer.cu:64-88.
+ * weight_diff (K,N) is ACCUMULATED into in the CPU code's n-ascending order
+ * (bit-identical; the reference's .cu uses atomicAdd).  bias_diff (N) likewise
+ * accumulated (BLAS-ordered in the reference: 1e-5).  Either may be NULL
+ * (= param_propagate_down false). */
+int mms_embed_backward_f32(int M, int N, int K, const float* index, const float* top_diff,
+                           float* weight_diff, float* bias_diff, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+size_t mms_embed_workspace_bytes(int M, int N);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,9 @@ _SIGNATURES = {
     "mms_triplet_euclid_step_f32": (_i, [_i, _i, _f, _f] + [_vp] * 11 + [_sz, _vp]),
     "mms_simcross_euclid_forward_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "mms_simcross_euclid_forward_backward_f16": (_i, [_i, _i] + [_vp] * 7),
+    "mms_embed_workspace_bytes": (_sz, [_i, _i]),
+    "mms_embed_forward_f32": (_i, [_i, _i, _i] + [_vp] * 5),
+    "mms_embed_backward_f32": (_i, [_i, _i, _i] + [_vp] * 5 + [_sz, _vp]),
     "mms_rank_workspace_bytes": (_sz, [_i]),
     "mms_rank_map_mrr_f32": (_i, [_i, _i] + [_vp] * 7 + [_sz, _vp]),
     "mms_rank_auc_f32": (_i, [_i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
@@ -244,3 +247,19 @@ def simcross_euclid_forward_backward_f16(q, a, top_diff, top, dq, da):
         N, D, _ptr(q, "q", dtype=h), _ptr(a, "a", dtype=h), _ptr(top_diff, "top_diff"),
         _ptr(top, "top"), _ptr(dq, "dq", dtype=h), _ptr(da, "da", dtype=h), _stream()),
         "mms_simcross_euclid_forward_backward_f16")
+
+
+def embed_forward(index, weight, top, bias=None):
+    M, (K, N) = index.numel(), weight.shape
+    check(lib().mms_embed_forward_f32(M, N, K, _ptr(index, "index"), _ptr(weight, "weight"),
+                                      _ptr(bias, "bias", True), _ptr(top, "top"), _stream()),
+          "mms_embed_forward_f32")
+
+
+def embed_backward(index, top_diff, weight_diff, bias_diff=None, ws=None):
+    M, (K, N) = index.numel(), weight_diff.shape
+    wsp, wsb = (ws or _default_ws).get(lib().mms_embed_workspace_bytes(M, N), index.device)
+    check(lib().mms_embed_backward_f32(M, N, K, _ptr(index, "index"), _ptr(top_diff, "top_diff"),
+                                       _ptr(weight_diff, "weight_diff", True),
+                                       _ptr(bias_diff, "bias_diff", True), wsp, wsb, _stream()),
+          "mms_embed_backward_f32")

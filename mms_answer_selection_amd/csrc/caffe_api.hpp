@@ -249,6 +249,18 @@ struct PairRankLossParameter {  // caffe.proto:479-481
   float margin_ = 1.0f;
   float margin() const { return margin_; }
 };
+struct EmbedParameter {  // caffe.proto:788-802 (+ the fork's weight_source, :801)
+  int num_output_ = 0, input_dim_ = 0;
+  bool bias_term_ = true;
+  FillerParameter weight_filler_, bias_filler_;
+  string weight_source_;
+  int num_output() const { return num_output_; }
+  int input_dim() const { return input_dim_; }
+  bool bias_term() const { return bias_term_; }
+  const FillerParameter& weight_filler() const { return weight_filler_; }
+  const FillerParameter& bias_filler() const { return bias_filler_; }
+  const string& weight_source() const { return weight_source_; }
+};
 struct MAPParameter {  // caffe.proto:422-424
   int fixed_axis_ = 1;
   int fixed_axis() const { return fixed_axis_; }
@@ -277,6 +289,8 @@ struct LayerParameter {  // caffe.proto:310-416 (subset)
   SimCrossParameter sim_cross_param_;
   SimMatrixParameter sim_matrix_param_;
   PairRankLossParameter pair_rank_loss_param_;
+  EmbedParameter embed_param_;
+  const EmbedParameter& embed_param() const { return embed_param_; }
   MAPParameter map_param_;
   MRRParameter mrr_param_;
   AUCParameter auc_param_;

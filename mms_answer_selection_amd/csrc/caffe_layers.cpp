@@ -325,6 +325,138 @@ class PairRankLossLayer : public LossLayer<Dtype> {
 INSTANTIATE_CLASS(PairRankLossLayer);
 REGISTER_LAYER_CLASS(PairRankLoss);
 
+// ======================================= Embed ===============================
+// Reference: include/caffe/layers/embed_layer.hpp, src/caffe/layers/embed_layer.cpp (the fork
+// adds `weight_source`, :46-113: word vectors loaded at set-up from a text / "all" / word2vec
+// binary file).  Blob order [weight (K,N), bias (N)].
+template <typename Dtype>
+class EmbedLayer : public Layer<Dtype> {
+ public:
+  explicit EmbedLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  const char* type() const override { return "Embed"; }
+  int ExactNumBottomBlobs() const override { return 1; }
+  int ExactNumTopBlobs() const override { return 1; }
+
+  void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    const EmbedParameter& p = this->layer_param_.embed_param();
+    N_ = p.num_output();
+    CHECK_GT(N_, 0) << "EmbedLayer num_output must be positive.";
+    K_ = p.input_dim();
+    CHECK_GT(K_, 0) << "EmbedLayer input_dim must be positive.";
+    bias_term_ = p.bias_term();
+    if (this->blobs_.size() > 0) {
+      LOG_INFO << "Skipping parameter initialization";
+    } else {
+      this->blobs_.resize(bias_term_ ? 2 : 1);
+      this->blobs_[0].reset(new Blob<Dtype>(vector<int>{K_, N_}));
+      shared_ptr<Filler<Dtype> > wf(GetFiller<Dtype>(p.weight_filler()));
+      wf->Fill(this->blobs_[0].get());
+      if (bias_term_) {
+        this->blobs_[1].reset(new Blob<Dtype>(vector<int>{N_}));
+        shared_ptr<Filler<Dtype> > bf(GetFiller<Dtype>(p.bias_filler()));
+        bf->Fill(this->blobs_[1].get());
+      }
+      if (!p.weight_source().empty()) LoadWeightSource(p.weight_source());
+    }
+    this->param_propagate_down_.resize(this->blobs_.size(), true);
+  }
+
+  void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    M_ = bottom[0]->count();
+    vector<int> top_shape = bottom[0]->shape();
+    top_shape.push_back(N_);
+    top[0]->Reshape(top_shape);
+    const size_t ws = mms_embed_workspace_bytes(M_, N_);
+    workspace_.Reshape(vector<int>{(int)((ws + sizeof(Dtype) - 1) / sizeof(Dtype))});
+  }
+
+ protected:
+  // embed_layer.cpp:46-113.  Rows are filled from row 0 in file order; the formats are
+  // told apart by the last three characters of the file name, as in the reference.
+  void LoadWeightSource(const string& path) {
+    Dtype* w = this->blobs_[0]->mutable_cpu_data();
+    const size_t cap = (size_t)K_ * N_;
+    size_t wi = 0;
+    const string ext = path.size() >= 3 ? path.substr(path.size() - 3) : string();
+    FILE* f = std::fopen(path.c_str(), ext == "txt" || ext == "all" ? "r" : "rb");
+    CHECK(f != nullptr) << "cannot open weight_source " << path;
+    char word[256];
+    if (ext == "txt") {                       // "<word> v1 ... vN" per line
+      while (std::fscanf(f, "%255s ", word) != EOF)
+        for (int i = 0; i < N_; ++i) {
+          float v = 0;
+          CHECK_EQ(std::fscanf(f, "%f ", &v), 1) << "truncated vector in " << path;
+          CHECK_LT(wi, cap) << "weight_source has more rows than input_dim";
+          w[wi++] = v;
+        }
+    } else if (ext == "all") {                // header "<float> <K-1> <N-1>", then "<id> v1 ... vN <word>"
+      float b1; int t1, t2;
+      CHECK_EQ(std::fscanf(f, "%f %d %d", &b1, &t1, &t2), 3);
+      CHECK_EQ(t1, K_ - 1);
+      CHECK_EQ(t2, N_ - 1);
+      while (std::fscanf(f, "%d ", &t1) != EOF) {
+        for (int i = 0; i < N_; ++i) {
+          float v = 0;
+          CHECK_EQ(std::fscanf(f, "%f ", &v), 1);
+          CHECK_LT(wi, cap);
+          w[wi++] = v;
+        }
+        CHECK_EQ(std::fscanf(f, "%255s", word), 1);
+      }
+    } else {                                  // word2vec binary: "<vocab> <dim>", then "<word> " + dim floats
+      long long vsize = 0, dim = 0;
+      CHECK_EQ(std::fscanf(f, "%lld", &vsize), 1);
+      CHECK_EQ(std::fscanf(f, "%lld", &dim), 1);
+      CHECK_EQ(dim, (long long)N_);
+      for (long long b = 0; b < vsize; ++b) {
+        int a = 0;
+        while (true) {
+          const int c = std::fgetc(f);
+          if (c == EOF || c == ' ') break;
+          if (a < 255 && c != '\n') word[a++] = (char)c;
+        }
+        for (long long i = 0; i < dim; ++i) {
+          float v = 0;
+          CHECK_EQ(std::fread(&v, sizeof(float), 1, f), (size_t)1);
+          CHECK_LT(wi, cap);
+          w[wi++] = v;
+        }
+      }
+    }
+    std::fclose(f);
+  }
+
+  void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
+  void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
+
+  // replaces embed_layer.cpp:135-152 / embed_layer.cu:42-62
+  void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    mms_check(mms_embed_forward_f32(M_, N_, K_, bottom[0]->gpu_data(), this->blobs_[0]->gpu_data(),
+                                    bias_term_ ? this->blobs_[1]->gpu_data() : nullptr,
+                                    top[0]->mutable_gpu_data(), nullptr),
+              "mms_embed_forward_f32");
+  }
+  // replaces embed_layer.cpp:155-180 / embed_layer.cu:64-88 (atomicAdd there; ordered sums here)
+  void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down,
+                    const vector<Blob<Dtype>*>& bottom) override {
+    CHECK(!propagate_down[0]) << "Can't backpropagate to EmbedLayer input.";
+    const bool pw = this->param_propagate_down_[0];
+    const bool pb = bias_term_ && this->param_propagate_down_[1];
+    if (!pw && !pb) return;
+    mms_check(mms_embed_backward_f32(M_, N_, K_, bottom[0]->gpu_data(), top[0]->gpu_diff(),
+                                     pw ? this->blobs_[0]->mutable_gpu_diff() : nullptr,
+                                     pb ? this->blobs_[1]->mutable_gpu_diff() : nullptr,
+                                     workspace_.mutable_gpu_data(),
+                                     (size_t)workspace_.count() * sizeof(Dtype), nullptr),
+              "mms_embed_backward_f32");
+  }
+  int M_ = 0, K_ = 0, N_ = 0;
+  bool bias_term_ = true;
+  Blob<Dtype> workspace_;
+};
+INSTANTIATE_CLASS(EmbedLayer);
+REGISTER_LAYER_CLASS(Embed);
+
 // ===================== MAP / MRR / AUC / RankAccuracy (forward only) =========
 // Reference: src/caffe/layers/{map,mrr,auc,rank_accuracy}_layer.cpp and their headers.
 // The reference has no GPU code for these (Forward_gpu falls back to Forward_cpu through
@@ -639,6 +771,20 @@ class Parser {
     if (n == "sim_matrix_param") {
       return message([&](const string& m) {
         if (m == "weight_filler") return filler(&lp->sim_matrix_param_.weight_filler_);
+        return false;
+      });
+    }
+    if (n == "embed_param") {
+      EmbedParameter* p = &lp->embed_param_;
+      return message([&](const string& m) {
+        if (m == "weight_filler") return filler(&p->weight_filler_);
+        if (m == "bias_filler") return filler(&p->bias_filler_);
+        Tok w;
+        if (!scalar(&w)) return false;
+        if (m == "num_output") return as_int(w, &p->num_output_);
+        if (m == "input_dim") return as_int(w, &p->input_dim_);
+        if (m == "bias_term") return as_bool(w, &p->bias_term_);
+        if (m == "weight_source") { p->weight_source_ = w.text; return true; }
         return false;
       });
     }

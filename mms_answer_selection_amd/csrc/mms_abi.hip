@@ -52,6 +52,12 @@ int rank_auc(int n, int dim, int fixed_axis, const float* prob, const float* lab
              int ignore_label, float* auc_out, void* ws, size_t ws_bytes, hipStream_t s);
 int rank_accuracy(int count, const float* a, const float* b, const float* label, float* out,
                   void* ws, size_t ws_bytes, hipStream_t s);
+// embed.hip
+size_t embed_workspace_bytes(int M, int N);
+int embed_forward(int M, int N, int K, const float* index, const float* weight, const float* bias,
+                  float* top, hipStream_t s);
+int embed_backward(int M, int N, int K, const float* index, const float* top_diff,
+                   float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes, hipStream_t s);
 }  // namespace mms
 
 using namespace mms;
@@ -269,6 +275,26 @@ int mms_rank_accuracy_f32(int count, const float* a, const float* b, const float
   if (count <= 0) return MMS_ERR_INVALID_ARG;
   if (!a || !b || !label || !acc_out) return MMS_ERR_INVALID_ARG;
   return rank_accuracy(count, a, b, label, acc_out, workspace, workspace_bytes, as_stream(stream));
+}
+
+size_t mms_embed_workspace_bytes(int M, int N) { return (M > 0 && N > 0) ? embed_workspace_bytes(M, N) : 0; }
+
+int mms_embed_forward_f32(int M, int N, int K, const float* index, const float* weight,
+                          const float* bias, float* top, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0 || (long long)M * N > 0x7fffffffLL) return MMS_ERR_INVALID_ARG;
+  if (M == 0) return MMS_OK;
+  if (!index || !weight || !top) return MMS_ERR_INVALID_ARG;
+  return embed_forward(M, N, K, index, weight, bias, top, as_stream(stream));
+}
+
+int mms_embed_backward_f32(int M, int N, int K, const float* index, const float* top_diff,
+                           float* weight_diff, float* bias_diff, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0 || (long long)M * N > 0x7fffffffLL) return MMS_ERR_INVALID_ARG;
+  if (M == 0 || (!weight_diff && !bias_diff)) return MMS_OK;
+  if (!index || !top_diff) return MMS_ERR_INVALID_ARG;
+  return embed_backward(M, N, K, index, top_diff, weight_diff, bias_diff, workspace, workspace_bytes,
+                        as_stream(stream));
 }
 
 }  // extern "C"

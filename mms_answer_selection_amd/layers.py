@@ -228,6 +228,12 @@ def PairRankLoss(**kw):
     return _make("PairRankLoss", "pair_rank_loss_param", **kw)
 
 
+def Embed(**kw):
+    """L.Embed(question, input_dim=V, num_output=Dw, weight_filler=..., weight_source=...)
+    (do_trec_qa_clean.py:461-466)."""
+    return _make("Embed", "embed_param", **kw)
+
+
 def MAP(**kw):
     """L.MAP(prob, label, group)  (do_trec_qa_clean.py:495)."""
     return _make("MAP", "map_param", **kw)

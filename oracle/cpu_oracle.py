@@ -217,3 +217,26 @@ def time_simcross_fwd_bwd(mode, q, a, top_diff, W=None, bias=None, iters=1):
     return lib().oracle_time_simcross_fwd_bwd_f32(
         C.c_int(mode), N, W1, W2, D, M, _p(q), _p(a), _p(W), _p(bias), _p(top_diff),
         _p(top), _p(n0), _p(n1), _p(dq), _p(da), _p(dW), _p(dbias), int(iters))
+
+
+def embed_forward(index, weight, bias=None):
+    """index (...) float, weight (K,N) -> top (..., N).  embed_layer.cpp:135-152."""
+    dt = weight.dtype
+    sfx, _ = _sfx(dt)
+    index, weight, bias = _c(index, dt), _c(weight, dt), _c(bias, dt)
+    M, N = int(index.size), int(weight.shape[1])
+    top = np.zeros(index.shape + (N,), dt)
+    getattr(lib(), "oracle_embed_forward" + sfx)(M, N, _p(index), _p(weight), _p(bias), _p(top))
+    return top
+
+
+def embed_backward(index, top_diff, weight_diff_in, bias_diff_in=None):
+    """-> (weight_diff, bias_diff), both ACCUMULATED into copies of the inputs.  embed_layer.cpp:155-180."""
+    dt = top_diff.dtype
+    sfx, _ = _sfx(dt)
+    index, top_diff = _c(index, dt), _c(top_diff, dt)
+    wd = np.array(weight_diff_in, dtype=dt, copy=True)
+    bd = None if bias_diff_in is None else np.array(bias_diff_in, dtype=dt, copy=True)
+    getattr(lib(), "oracle_embed_backward" + sfx)(int(index.size), int(wd.shape[1]), _p(index),
+                                                  _p(top_diff), _p(wd), _p(bd))
+    return wd, bd

@@ -315,3 +315,39 @@ Dtype SFX(oracle_rank_accuracy)(int count, const Dtype* a, const Dtype* b,
     acc += (label[i] * (a[i] - b[i])) > 0 ? 1 : 0;
   return acc / count;
 }
+
+/* ---------------------------------------------------------------------------
+ * Embed (the step before the path).
+ * Reference: embed_layer.cpp:135-152 (forward), :155-180 (backward).
+ *   forward : top[n] = weight[int(index[n])] (caffe_copy), then with a bias
+ *             term  top = 1*(ones x bias) + 1*top  (gemm, K = 1).
+ *   backward: weight_diff[int(index[n])] += top_diff[n] for n ASCENDING
+ *             (caffe_axpy, alpha 1: y = 1*x + y), accumulating into the
+ *             existing diff; bias_diff += top_diff^T ones (gemv).
+ * ------------------------------------------------------------------------- */
+void SFX(oracle_embed_forward)(int M, int N, const Dtype* index, const Dtype* weight,
+                               const Dtype* bias, Dtype* top) {
+  for (int n = 0; n < M; ++n) {
+    const int idx = (int)index[n];
+    memcpy(top + (size_t)n * N, weight + (size_t)idx * N, sizeof(Dtype) * N);
+  }
+  if (bias)
+    for (int n = 0; n < M; ++n)
+      for (int d = 0; d < N; ++d)
+        top[(size_t)n * N + d] = (Dtype)1 * ((Dtype)1 * bias[d]) + (Dtype)1 * top[(size_t)n * N + d];
+}
+
+void SFX(oracle_embed_backward)(int M, int N, const Dtype* index, const Dtype* top_diff,
+                                Dtype* weight_diff, Dtype* bias_diff) {
+  for (int n = 0; n < M; ++n) {
+    const int idx = (int)index[n];
+    for (int d = 0; d < N; ++d)
+      weight_diff[(size_t)idx * N + d] = (Dtype)1 * top_diff[(size_t)n * N + d] + weight_diff[(size_t)idx * N + d];
+  }
+  if (bias_diff)
+    for (int d = 0; d < N; ++d) {
+      Dtype s = 0;
+      for (int n = 0; n < M; ++n) s += top_diff[(size_t)n * N + d] * (Dtype)1;
+      bias_diff[d] = (Dtype)1 * s + (Dtype)1 * bias_diff[d];
+    }
+}

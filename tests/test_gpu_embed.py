@@ -1,0 +1,99 @@
+"""GPU parity for the Embed layer: gather forward, ordered
+scatter-add backward (bit-exact vs the CPU order), the weight_source loaders,
+and the Embed -> SimCross chain the driver builds (do_trec_qa_clean.py:461-468)."""
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from util import TOL, assert_bitexact, assert_close, rng
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize("cfg", [(50 * 80, 50, 3000, True), (37, 300, 11, False), (1, 4, 1, True),
+                                 (1517 * 8, 50, 20000, True)])
+def test_embed_forward_backward(cfg, oracle, hiplib):
+    from mms_answer_selection_amd import capi
+    M, N, K, use_bias = cfg
+    r = rng(M + N)
+    index = r.integers(0, K, M)
+    index[r.uniform(size=M) < 0.6] = K - 1            # the zero-pad word id dominates a TREC-QA batch
+    index = index.astype(np.float32)
+    weight = r.uniform(-0.08, 0.08, (K, N)).astype(np.float32)
+    bias = r.standard_normal(N).astype(np.float32) if use_bias else None
+    top_ref = oracle.embed_forward(index, weight, bias)
+    top = torch.full((M, N), float("nan"), device="cuda")
+    capi.embed_forward(dev(index), dev(weight), top, bias=dev(bias))
+    assert_bitexact(top.cpu().numpy(), top_ref, "top")
+    dT = r.standard_normal((M, N)).astype(np.float32)
+    wd0 = r.standard_normal((K, N)).astype(np.float32)   # diffs ACCUMULATE (embed_layer.cpp:170,177)
+    bd0 = r.standard_normal(N).astype(np.float32) if use_bias else None
+    wd_ref, bd_ref = oracle.embed_backward(index, dT, wd0, bd0)
+    wd, bd = dev(wd0), dev(bd0)
+    capi.embed_backward(dev(index), dev(dT), wd, bd)
+    assert_bitexact(wd.cpu().numpy(), wd_ref, "weight_diff (n-ascending sums)")
+    if use_bias:
+        assert_close(bd.cpu().numpy(), bd_ref, TOL, "bias_diff")
+    wd2 = dev(wd0)
+    capi.embed_backward(dev(index), dev(dT), wd2, None)   # same bits on a second run (no atomics)
+    assert_bitexact(wd2.cpu().numpy(), wd_ref)
+
+
+def test_embed_layer_weight_sources_and_chain(tmp_path, oracle, hiplib):
+    from mms_answer_selection_amd import layers as L
+    L.lib(); L.set_mode_gpu()
+    r = rng(8)
+    V, Dw = 12, 50
+    vecs = r.uniform(-1, 1, (V, Dw)).astype(np.float32)
+    # 1. GloVe-style text file: "<word> v1 ... vD" (do_trec_qa_clean.py:283-289)
+    txt = tmp_path / "wiki_dict.txt"
+    txt.write_text("".join("w%d %s\n" % (i, " ".join("%.6f" % v for v in vecs[i])) for i in range(V)))
+    # 2. the ".all" format: header "<float> <K-1> <N-1>", rows "<id> v... <word>"
+    allf = tmp_path / "dict.all"
+    allf.write_text("0.5 %d %d\n" % (V + 2 - 1, Dw - 1) +
+                    "".join("%d %s w%d\n" % (i, " ".join("%.6f" % v for v in vecs[i]), i) for i in range(V)))
+    # 3. word2vec binary
+    binf = tmp_path / "vectors.bin"
+    with open(binf, "wb") as f:
+        f.write(b"%d %d\n" % (V, Dw))
+        for i in range(V):
+            f.write(b"w%d " % i + struct.pack("%df" % Dw, *vecs[i]) + b"\n")
+    expect_txt = np.array([[float("%.6f" % v) for v in row] for row in vecs], np.float32)
+    for path, expect in ((txt, expect_txt), (allf, expect_txt), (binf, vecs)):
+        lay = L.Embed(input_dim=V + 2, num_output=Dw, bias_term=False, weight_source=str(path),
+                      weight_filler=dict(type="constant", value=7.0))
+        idx = L.Blob((3, 5))
+        top = L.Blob()
+        lay.SetUp([idx], [top])
+        W = lay.blobs[0].data
+        assert W.shape == (V + 2, Dw)
+        assert_bitexact(W[:V], expect, str(path))
+        assert (W[V:] == 7.0).all()                     # +2 rows (unknown, zero-pad) keep the filler
+        assert top.shape == (3, 5, Dw)
+    # Embed(question), Embed(answer) -> SimCross, as network_v4 wires them
+    q_idx = r.integers(0, V + 2, (4, 6)).astype(np.float32)
+    a_idx = r.integers(0, V + 2, (4, 6)).astype(np.float32)
+    bq, ba, tq, ta, ts = L.Blob((4, 6)), L.Blob((4, 6)), L.Blob(), L.Blob(), L.Blob()
+    bq.data[...] = q_idx
+    ba.data[...] = a_idx
+    lay.SetUp([bq], [tq]); lay.Forward([bq], [tq])
+    lay.Forward([ba], [ta])                             # shared weights ('w2v-weights')
+    sim = L.SimCross()
+    sim.SetUp([tq, ta], [ts]); sim.Forward([tq, ta], [ts])
+    Wnp = lay.blobs[0].data.copy()
+    top_ref, _, _ = oracle.simcross_forward(1, Wnp[q_idx.astype(int)], Wnp[a_idx.astype(int)])
+    assert_bitexact(ts.data, top_ref, "SimCross on embedded words")
+    # backward through SimCross then Embed
+    ts.diff[...] = r.standard_normal(ts.shape).astype(np.float32)
+    sim.Backward([ts], [True, True], [tq, ta])
+    lay.blobs[0].diff[...] = 0
+    dq = tq.diff.copy()
+    lay.Backward([tq], [False], [bq])
+    wd_ref, _ = oracle.embed_backward(q_idx, dq.reshape(-1, Dw), np.zeros_like(Wnp))
+    assert_bitexact(lay.blobs[0].diff, wd_ref)
