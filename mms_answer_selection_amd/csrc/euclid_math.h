@@ -70,14 +70,16 @@ __device__ __forceinline__ float euclid_tt(const EuclidCoef& k, float diff) {
 }
 
 // Four elements that share one coefficient set (a float4 of one pair's row):
-// same arithmetic as euclid_tt, but the rare-case tests are folded into ONE
-// wave-level branch per float4 and made cheaper:
+// same arithmetic as euclid_tt, with the rare-case tests made cheaper and
+// RETURNED instead of branched on, so that a caller can run several float4s
+// as one straight-line block (independent instruction chains interleave) and
+// take a single wave-level branch for all of them:
 //   * "result could be float-subnormal" needs |num * rcp| < 2^-126; when
 //     |rcp| >= 1 (always true for T in (0,1]: |den| <= 1) that requires num
 //     itself to be subnormal -- one v_cmp_class per element; a pair whose
 //     |rcp| < 1 (only possible for caller-supplied T outside (0,1]) takes the
 //     exact path wholesale.
-__device__ __forceinline__ float4 euclid_tt4(const EuclidCoef& k, const float4& d) {
+__device__ __forceinline__ float4 euclid_tt4_fast(const EuclidCoef& k, const float4& d, bool& risky) {
   const float n0 = k.c * d.x, n1 = k.c * d.y, n2 = k.c * d.z, n3 = k.c * d.w;
   const double p0 = (double)n0 * k.rcp, p1 = (double)n1 * k.rcp;
   const double p2 = (double)n2 * k.rcp, p3 = (double)n3 * k.rcp;
@@ -88,12 +90,20 @@ __device__ __forceinline__ float4 euclid_tt4(const EuclidCoef& k, const float4& 
     return (lo - 0x0fffffc0u) <= 128u;
   };
   auto subn = [](float x) -> bool { return __builtin_isfpclass(x, 0x0090 /* +-subnormal */); };
-  const bool risky = near(p0) || near(p1) || near(p2) || near(p3) || subn(n0) || subn(n1) ||
-                     subn(n2) || subn(n3) || !(fabs(k.rcp) >= 1.0);
-  if (risky) {
-    r.x = (float)((double)n0 / k.den); r.y = (float)((double)n1 / k.den);
-    r.z = (float)((double)n2 / k.den); r.w = (float)((double)n3 / k.den);
-  }
+  risky = near(p0) || near(p1) || near(p2) || near(p3) || subn(n0) || subn(n1) || subn(n2) ||
+          subn(n3) || !(fabs(k.rcp) >= 1.0);
+  return r;
+}
+__device__ __forceinline__ float4 euclid_tt4_exact(const EuclidCoef& k, const float4& d) {
+  float4 r;
+  r.x = euclid_tt_exact(k.c, k.den, d.x); r.y = euclid_tt_exact(k.c, k.den, d.y);
+  r.z = euclid_tt_exact(k.c, k.den, d.z); r.w = euclid_tt_exact(k.c, k.den, d.w);
+  return r;
+}
+__device__ __forceinline__ float4 euclid_tt4(const EuclidCoef& k, const float4& d) {
+  bool risky;
+  float4 r = euclid_tt4_fast(k, d, risky);
+  if (risky) r = euclid_tt4_exact(k, d);
   return r;
 }
 

@@ -26,6 +26,20 @@
 
 namespace mms {
 
+// Dev-only phase stamps (tools/stampbench.hip builds this file with -DMMS_STAMPS): lane 0 of
+// every wave of the fused rows kernel records s_memtime at its phase boundaries into a
+// buffer no other code reads.  Compiled out of the product.
+#ifdef MMS_STAMPS
+__device__ unsigned long long* mms_stamp_buf = nullptr;
+#define MMS_STAMP(k)                                                                        \
+  do {                                                                                      \
+    if (mms_stamp_buf && (threadIdx.x & 63) == 0)                                           \
+      mms_stamp_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define MMS_STAMP(k) do {} while (0)
+#endif
+
 // =============================== rows geometry ==============================
 
 // ---- wave-centric kernel (the fast path) ------------------------------------
@@ -62,6 +76,7 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
   const int st4 = spec_stride4(D4);
   float4* sq4 = lds4 + (size_t)wave * RW * st4;
 
+  MMS_STAMP(0);
   float4 x[NIT], y[NIT], df[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -70,6 +85,7 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
     x[it] = q4[ii];
     y[it] = a4[ii];
   }
+  MMS_STAMP(1);
   // this lane's pair for the chain / coefficient work
   const int grp = lane / LPR, j = lane % LPR;
   const int grow = min(grp, rows - 1);           // a missing 2nd pair mirrors the 1st (results unused)
@@ -78,9 +94,9 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
   float g = 0.f;
   if (BWD) g = top_diff[row0 + grow];
 
-  float pred1[RW], pred2[RW];
+  float2v pred[RW];                              // per pair: (pred1, pred2) partial sums
 #pragma unroll
-  for (int r = 0; r < RW; ++r) { pred1[r] = 0.f; pred2[r] = 0.f; }
+  for (int r = 0; r < RW; ++r) pred[r] = (float2v){0.f, 0.f};
   const int h4 = spec_h4(D4);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -91,21 +107,24 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
       float4 s;
       s.x = df[it].x * df[it].x; s.y = df[it].y * df[it].y;
       s.z = df[it].z * df[it].z; s.w = df[it].w * df[it].w;
-      // image slot of this float4 and its tree-sum contribution to the predictions of
-      // the pair it belongs to
-      const int r = (RW == 2 && i >= D4) ? 1 : 0;
-      const int ir = i - r * D4;
-      if (i < n4) sq4[r * st4 + ir] = s;
+      // image slot of this float4 (pair r's image starts at r*st4) and its tree-sum
+      // contribution to the two predictions of the pair it belongs to
+      const bool r1 = (RW == 2) && (i >= D4);
+      const int ir = r1 ? i - D4 : i;
+      if (i < n4) sq4[r1 ? i + (st4 - D4) : i] = s;
       const float s4 = (i < n4) ? (s.x + s.y) + (s.z + s.w) : 0.f;
-      const float c1 = (ir < h4) ? s4 : 0.f, c2 = (ir < 2 * h4) ? s4 : 0.f;
-      pred1[0] += (r == 0) ? c1 : 0.f;
-      pred2[0] += (r == 0) ? c2 : 0.f;
-      if (RW == 2) {
-        pred1[RW - 1] += (r == 1) ? c1 : 0.f;
-        pred2[RW - 1] += (r == 1) ? c2 : 0.f;
-      }
+      float2v c;                                   // (segment-0 part, segments-0-1 part)
+      c.x = (ir < h4) ? s4 : 0.f;
+      c.y = (ir < 2 * h4) ? s4 : 0.f;
+      const float2v z2 = {0.f, 0.f};
+      pred[0] += r1 ? z2 : c;
+      if (RW == 2) pred[RW - 1] += r1 ? c : z2;
     }
   }
+#ifdef MMS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MMS_STAMP(2);
   if (FWD) {
     // zero pad at the end of each image (0..2 entries)
     const int npad = st4 - D4;
@@ -113,15 +132,17 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
     float my1 = 0.f, my2 = 0.f;
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-      const float p1 = wave_sum(pred1[r]), p2 = wave_sum(pred2[r]);
+      const float p1 = wave_sum(pred[r].x), p2 = wave_sum(pred[r].y);
       if (r == grow) { my1 = p1; my2 = p2; }
     }
     wave_lds_sync();
+    MMS_STAMP(3);
 #if defined(MMS_ABLATE) && MMS_ABLATE >= 1   // dev-only timing ablation (tools/ablate.sh): no chain
     const float dist = my2;
 #else
     const float dist = chain_sum_speculative<LPR>(sq4 + grow * st4, D4, my1, my2, j, grp * LPR);
 #endif
+    MMS_STAMP(4);
     T = 1.0f / (1.0f + sqrtf(dist));            // :106-107
     if (j == 0 && grp < rows) top_out[row0 + grp] = T;
   }
@@ -136,22 +157,45 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
     kr[r].den = __shfl(mine.den, r * LPR, 64);
     kr[r].rcp = __shfl(mine.rcp, r * LPR, 64);
   }
+  MMS_STAMP(5);
   float4* dq4 = reinterpret_cast<float4*>(dq) + base4;
   float4* da4 = reinterpret_cast<float4*>(da) + base4;
+  // all NIT float4s as ONE straight-line block (their instruction chains interleave),
+  // then a single wave-level branch for the rare exact re-computation
+  float4 t[NIT];
+  bool any_risky = false;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane + 64 * it;
+    const EuclidCoef& k = (RW == 2 && i >= D4) ? kr[RW - 1] : kr[0];
+    bool risky;
+    t[it] = euclid_tt4_fast(k, df[it], risky);
+    any_risky |= risky && (i < n4);
+  }
+  if (any_risky) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = lane + 64 * it;
+      const EuclidCoef& k = (RW == 2 && i >= D4) ? kr[RW - 1] : kr[0];
+      t[it] = euclid_tt4_exact(k, df[it]);
+    }
+  }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = lane + 64 * it;
     if (i >= n4) break;
-    EuclidCoef k = kr[0];
-    if (RW == 2 && i >= D4) k = kr[1];
-    const float4 t = euclid_tt4(k, df[it]);
     // dq = 0 + tt ; da = 0 + (-tt)   (:176-177 zero, :219-220 accumulate once)
     float4 o0, o1;
-    o0.x = 0.f + t.x; o0.y = 0.f + t.y; o0.z = 0.f + t.z; o0.w = 0.f + t.w;
-    o1.x = 0.f + (-t.x); o1.y = 0.f + (-t.y); o1.z = 0.f + (-t.z); o1.w = 0.f + (-t.w);
+    o0.x = 0.f + t[it].x; o0.y = 0.f + t[it].y; o0.z = 0.f + t[it].z; o0.w = 0.f + t[it].w;
+    o1.x = 0.f + (-t[it].x); o1.y = 0.f + (-t[it].y); o1.z = 0.f + (-t[it].z); o1.w = 0.f + (-t[it].w);
     dq4[i] = o0;
     da4[i] = o1;
   }
+  MMS_STAMP(6);
+#ifdef MMS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MMS_STAMP(7);
 }
 
 // ---- fp16 storage, fp32 arithmetic (BASELINE cfg 5) --------------------------

@@ -3,7 +3,7 @@
 # and run tools/membench against each (outputs are WRONG in ablated builds; only time matters).
 set -e
 ROOT=$(pwd)
-SRCS="mms_answer_selection_amd/csrc/mms_abi.hip mms_answer_selection_amd/csrc/simcross_elementwise.hip mms_answer_selection_amd/csrc/bilinear.hip mms_answer_selection_amd/csrc/pairrank.hip"
+SRCS=$(ls mms_answer_selection_amd/csrc/*.hip)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -I include -I mms_answer_selection_amd/csrc"
 for v in "$@"; do
   mkdir -p /tmp/abl$v
