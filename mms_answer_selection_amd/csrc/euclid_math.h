@@ -159,6 +159,12 @@ __device__ __forceinline__ float chain_sum_lds(const float4* r4, int n4, float i
 // (profiles/r01_chainbench…): ~10.5 ticks per dependent packed add however many
 // waves share the SIMD, against ~14 for a plain add at two waves per SIMD.
 typedef float float2v __attribute__((ext_vector_type(2)));
+#ifdef MMS_STAMPS   // dev-only: speculation-miss counter (tools/stampbench.hip)
+__device__ unsigned mms_miss_count = 0;
+#define MMS_COUNT_MISS() do { if ((threadIdx.x & 31) == 0) atomicAdd(&mms_miss_count, 1u); } while (0)
+#else
+#define MMS_COUNT_MISS() do {} while (0)
+#endif
 __device__ __forceinline__ float2v chain_sum_lds_pk(const float4* r4, int n4, float2v init) {
   float2v s = init;
   auto step = [&](const float4& v) {
@@ -254,14 +260,14 @@ __device__ __forceinline__ float chain_sum_speculative(const float4* img4, int D
   const int l1 = lead + 1 + ((hit1 ? k1 : 0) >> 1);
   const float e1x = __shfl(end.x, l1, 64), e1y = __shfl(end.y, l1, 64);
   float s2 = (k1 & 1) ? e1y : e1x;
-  if (!hit1) s2 = chain_sum_lds(img4 + h4, h4, s1);                       // re-walk, exact
+  if (!hit1) { MMS_COUNT_MISS(); s2 = chain_sum_lds(img4 + h4, h4, s1); }   // re-walk, exact
   // segment 1 -> 2
   const int k2 = __float_as_int(s2) - __float_as_int(pred2) + P::H2;
   const bool hit2 = (k2 >= 0) && (k2 <= 2 * P::H2);
   const int l2 = lead + 1 + P::L1 + ((hit2 ? k2 : 0) >> 1);
   const float e2x = __shfl(end.x, l2, 64), e2y = __shfl(end.y, l2, 64);
   float s3 = (k2 & 1) ? e2y : e2x;
-  if (!hit2) s3 = chain_sum_lds(img4 + 2 * h4, h4, s2);
+  if (!hit2) { MMS_COUNT_MISS(); s3 = chain_sum_lds(img4 + 2 * h4, h4, s2); }
   __builtin_amdgcn_s_setprio(0);
   return s3;
 }

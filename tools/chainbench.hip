@@ -42,6 +42,22 @@ __global__ void chain_regs_pk(const float* in, float* out, unsigned long long* c
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+// dependent v_mfma_f32_16x16x4_f32 with B == 1: four sequential fp32 adds per instruction
+__global__ void chain_mfma(const float* in, float* out, unsigned long long* cyc, int reps) {
+  float a[8];
+  for (int i = 0; i < 8; ++i) a[i] = in[(threadIdx.x + i) & 31];
+  v4f_t acc = {in[32], in[33], in[34], in[35]};
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int r = 0; r < reps; ++r) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], 1.0f, acc, 0, 0, 0);
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 __global__ void chain_lds(const float* in, float* out, unsigned long long* cyc, int D4) {
   __shared__ float4 sq[4][256];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -80,6 +96,9 @@ int main() {
     hipLaunchKernelGGL(chain_regs_pk<64>, dim3(1), dim3(64), 0, 0, in, out, cyc, reps); report("PACKED regs, 1 wave on chip", 1, 320);
     hipLaunchKernelGGL(chain_regs_pk<64>, dim3(256), dim3(256), 0, 0, in, out, cyc, reps); report("PACKED regs, 1 wave/SIMD all CUs", 256, 320);
     hipLaunchKernelGGL(chain_regs_pk<64>, dim3(512), dim3(256), 0, 0, in, out, cyc, reps); report("PACKED regs, 2 waves/SIMD all CUs", 512, 320);
+    hipLaunchKernelGGL(chain_mfma, dim3(1), dim3(64), 0, 0, in, out, cyc, 40); report("MFMA 16x16x4 dependent, 1 wave (per MFMA = 4 adds)", 1, 320);
+    hipLaunchKernelGGL(chain_mfma, dim3(256), dim3(256), 0, 0, in, out, cyc, 40); report("MFMA 16x16x4 dependent, 1 wave/SIMD all CUs", 256, 320);
+    hipLaunchKernelGGL(chain_mfma, dim3(512), dim3(256), 0, 0, in, out, cyc, 40); report("MFMA 16x16x4 dependent, 2 waves/SIMD all CUs", 512, 320);
     hipLaunchKernelGGL(chain_lds, dim3(1), dim3(64), 0, 0, in, out, cyc, 75); report("lds-fed D4=75, 1 wave", 1, 300);
     hipLaunchKernelGGL(chain_lds, dim3(512), dim3(256), 0, 0, in, out, cyc, 75); report("lds-fed D4=75, 2 waves/SIMD all CUs", 512, 300);
   }

@@ -55,6 +55,9 @@ int main() {
       printf("%-24s %8.0f %8.0f %8.0f %8.0f %8.0f\n", names[k], v[0], v[waves / 10], v[waves / 2], v[waves * 9 / 10], v[waves - 1]);
     }
     // per-wave phase durations (median)
+    unsigned miss = 0;
+    CK(hipMemcpyFromSymbol(&miss, HIP_SYMBOL(mms::mms_miss_count), sizeof(miss)));
+    printf("speculation misses so far (all launches): %u\n", miss);
     printf("median per-wave durations:");
     for (int k = 1; k < 8; ++k) {
       std::vector<double> v(waves);
