@@ -153,9 +153,17 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
   EuclidCoef kr[RW];
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
-    kr[r].c = __shfl(mine.c, r * LPR, 64);
-    kr[r].den = __shfl(mine.den, r * LPR, 64);
-    kr[r].rcp = __shfl(mine.rcp, r * LPR, 64);
+    // lane r*LPR is a compile-time lane: v_readlane (no LDS round trip as with ds_bpermute)
+    kr[r].c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c), r * LPR));
+    {
+      const long long dn = __double_as_longlong(mine.den), rc = __double_as_longlong(mine.rcp);
+      const unsigned dlo = __builtin_amdgcn_readlane((int)(unsigned)dn, r * LPR);
+      const unsigned dhi = __builtin_amdgcn_readlane((int)(unsigned)(dn >> 32), r * LPR);
+      const unsigned rlo = __builtin_amdgcn_readlane((int)(unsigned)rc, r * LPR);
+      const unsigned rhi = __builtin_amdgcn_readlane((int)(unsigned)(rc >> 32), r * LPR);
+      kr[r].den = __longlong_as_double((long long)(((unsigned long long)dhi << 32) | dlo));
+      kr[r].rcp = __longlong_as_double((long long)(((unsigned long long)rhi << 32) | rlo));
+    }
   }
   MMS_STAMP(5);
   float4* dq4 = reinterpret_cast<float4*>(dq) + base4;
