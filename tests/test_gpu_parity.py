@@ -83,6 +83,40 @@ def test_euclid_forward_backward_bitexact(shape, oracle, hiplib):
     assert_bitexact(host(ga2), da_ref, "fused da")
 
 
+def test_euclid_shape_fuzz_bitexact(oracle, hiplib):
+    """Many small random geometries through every dispatch branch (wave kernel with 1 or 2
+    pairs per wave and NIT 1..4, generic rows kernel, cross tiles of every register-tile size,
+    tiled and generic cross backward): everything Euclidean stays bit-exact."""
+    from mms_answer_selection_amd import capi
+    r = rng(2024)
+    dims = [1, 2, 3, 4, 5, 8, 12, 16, 20, 36, 44, 52, 64, 100, 128, 132, 256, 300, 404, 512, 768, 1020, 1024]
+    shapes = []
+    for _ in range(28):
+        D = int(r.choice(dims))
+        if r.uniform() < 0.5:
+            shapes.append((int(r.integers(1, 70)), 1, 1, D))
+        else:
+            shapes.append((int(r.integers(1, 6)), int(r.integers(1, 48)), int(r.integers(1, 48)), min(D, 132)))
+    for (N, W1, W2, D) in shapes:
+        q, a = qa(r, N, W1, W2, D)
+        dT = r.standard_normal((N, 1, W1, W2)).astype(np.float32)
+        top_ref, _, _ = oracle.simcross_forward(1, q, a)
+        dq_ref, da_ref, _, _ = oracle.simcross_backward(1, q, a, top_ref, dT)
+        qd, ad, dTd = dev(q), dev(a), dev(dT)
+        top, gq, ga = nan_like(top_ref.shape), nan_like(q.shape), nan_like(a.shape)
+        capi.simcross_forward_backward(1, qd, ad, dTd, top, gq, ga)
+        what = "shape %s" % ((N, W1, W2, D),)
+        assert_bitexact(host(top), top_ref, what + " top")
+        assert_bitexact(host(gq), dq_ref, what + " dq")
+        assert_bitexact(host(ga), da_ref, what + " da")
+        top2, gq2, ga2 = nan_like(top_ref.shape), nan_like(q.shape), nan_like(a.shape)
+        capi.simcross_forward(1, qd, ad, top2)
+        capi.simcross_backward(1, qd, ad, top2, dTd, gq2, ga2)
+        assert_bitexact(host(top2), top_ref, what + " top (two calls)")
+        assert_bitexact(host(gq2), dq_ref, what + " dq (two calls)")
+        assert_bitexact(host(ga2), da_ref, what + " da (two calls)")
+
+
 @pytest.mark.parametrize("D", [300, 1024])
 def test_euclid_speculation_miss_falls_back_exactly(D, oracle, hiplib):
     """Adversarial rows for the speculative chain (euclid_math.h): one large square
