@@ -640,10 +640,15 @@ __global__ __launch_bounds__(256) void cross_bwd_tiled_kernel(
     const float* __restrict__ q, const float* __restrict__ a,
     const float* __restrict__ top, const float* __restrict__ top_diff,
     const float* __restrict__ norm0, const float* __restrict__ norm1,
-    float* __restrict__ dq, float* __restrict__ da, int W1, int W2, int D, int nchunks) {
+    float* __restrict__ dq, float* __restrict__ da, int W1, int W2, int D, int nchunks, int split) {
   extern __shared__ double lds_d[];
   constexpr int LS = kBwdDC + 1;
-  const int n = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+  // split: blockIdx.x = (n * nchunks + chunk) * 2 + pass -- the dq pass and the da pass of one
+  // (pair, chunk) run as separate workgroups (twice the parallelism; small batches).
+  // Otherwise one workgroup does both and the tables are built once (large batches).
+  const int bid = split ? (blockIdx.x >> 1) : blockIdx.x;
+  const bool do_dq = !split || (blockIdx.x & 1) == 0, do_da = !split || (blockIdx.x & 1) == 1;
+  const int n = bid / nchunks, chunk = bid % nchunks;
   const int d0 = chunk * kBwdDC, dn = min(kBwdDC, D - d0);
   const int JK = W1 * W2;
   // carve: doubles first (8-byte aligned), then floats
@@ -687,7 +692,7 @@ __global__ __launch_bounds__(256) void cross_bwd_tiled_kernel(
 
   float* dqn = dq + (size_t)n * W1 * D;
   float* dan = da + (size_t)n * W2 * D;
-  for (int e = threadIdx.x; e < W1 * kBwdDC; e += 256) {
+  for (int e = threadIdx.x; do_dq && e < W1 * kBwdDC; e += 256) {
     const int j = e >> 5, dd = e & 31;
     if (dd >= dn) continue;
     const float qv = qs[j * LS + dd];
@@ -705,7 +710,7 @@ __global__ __launch_bounds__(256) void cross_bwd_tiled_kernel(
     }
     dqn[(size_t)j * D + d0 + dd] = acc;
   }
-  for (int e = threadIdx.x; e < W2 * kBwdDC; e += 256) {
+  for (int e = threadIdx.x; do_da && e < W2 * kBwdDC; e += 256) {
     const int k = e >> 5, dd = e & 31;
     if (dd >= dn) continue;
     const float av = as[k * LS + dd];
@@ -868,15 +873,17 @@ int simcross_elementwise_backward(int mode, int N, int W1, int W2, int D,
                          top_diff, const_cast<float*>(top), const_cast<float*>(norm0),
                          const_cast<float*>(norm1), dq, da, N, D);
   } else if (cross_bwd_tiled_lds(mode, W1, W2) <= 64 * 1024 &&
-             (long long)N * ((D + kBwdDC - 1) / kBwdDC) <= 0x7fffffffLL) {
+             2LL * N * ((D + kBwdDC - 1) / kBwdDC) <= 0x7fffffffLL) {
     const int nchunks = (D + kBwdDC - 1) / kBwdDC;
     const size_t lds = cross_bwd_tiled_lds(mode, W1, W2);
+    const int split = ((long long)N * nchunks < 1024) ? 1 : 0;     // fill the chip when the batch is small
+    const unsigned grid = (unsigned)((split ? 2LL : 1LL) * N * nchunks);
     if (mode == 1)
-      hipLaunchKernelGGL((cross_bwd_tiled_kernel<1>), dim3((unsigned)(N * nchunks)), dim3(256), lds,
-                         s, q, a, top, top_diff, nullptr, nullptr, dq, da, W1, W2, D, nchunks);
+      hipLaunchKernelGGL((cross_bwd_tiled_kernel<1>), dim3(grid), dim3(256), lds, s, q, a, top,
+                         top_diff, nullptr, nullptr, dq, da, W1, W2, D, nchunks, split);
     else
-      hipLaunchKernelGGL((cross_bwd_tiled_kernel<0>), dim3((unsigned)(N * nchunks)), dim3(256), lds,
-                         s, q, a, top, top_diff, norm0, norm1, dq, da, W1, W2, D, nchunks);
+      hipLaunchKernelGGL((cross_bwd_tiled_kernel<0>), dim3(grid), dim3(256), lds, s, q, a, top,
+                         top_diff, norm0, norm1, dq, da, W1, W2, D, nchunks, split);
   } else if (mode == 1) {
     hipLaunchKernelGGL((cross_bwd_kernel<1>), dim3(N), dim3(256), 0, s, q, a, top, top_diff,
                        nullptr, nullptr, dq, da, W1, W2, D);
