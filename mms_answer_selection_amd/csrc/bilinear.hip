@@ -168,8 +168,8 @@ constexpr int FH = FK / 2;       // k values per half-wave per tile
 
 template <bool A_KVEC, bool B_JVEC, bool KSCALE>
 __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
-  __shared__ float As[FM * LSK];
-  __shared__ float Bs[FK * LSJ];
+  __shared__ float As2[2][FM * LSK];            // double-buffered: one barrier per k-tile
+  __shared__ float Bs2[2][FK * LSJ];
   const int z = blockIdx.z;
   const int ks = z % g.ksplit;
   const int b1 = (z / g.ksplit) % g.nb1;
@@ -179,7 +179,20 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
   float* C = g.C + b0 * g.c_b0 + b1 * g.c_b1 + ks * g.c_ks;
   const int kbeg = ks * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
-  const int i0 = blockIdx.y * FM, j0 = blockIdx.x * FN;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own
+  // L2), so linear ids that differ by 8 share an L2.  Remap so that CONSECUTIVE tiles -- the
+  // column tiles of one row panel, which re-read the same A rows -- land on one XCD.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int total = gridDim.x * gridDim.y;
+    if ((total & 7) == 0) {
+      const int id = by * gridDim.x + bx;
+      const int tl = (id & 7) * (total >> 3) + (id >> 3);
+      by = tl / gridDim.x;
+      bx = tl - by * gridDim.x;
+    }
+  }
+  const int i0 = by * FM, j0 = bx * FN;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
 
@@ -222,7 +235,9 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
       pb[sl] += b_step;
     }
   };
-  auto store = [&]() {
+  auto store = [&](int buf) {
+    float* As = As2[buf];
+    float* Bs = Bs2[buf];
 #pragma unroll
     for (int sl = 0; sl < FSL; ++sl) {
       if (A_KVEC) {
@@ -248,11 +263,14 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
 
   if (kbeg < kend) {
     load(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += FK) {
-      __syncthreads();
-      store();
-      __syncthreads();
-      if (k0 + FK < kend) load(k0 + FK);
+    store(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += FK, cur ^= 1) {
+      const bool more = k0 + FK < kend;
+      if (more) load(k0 + FK);                    // global -> registers, in flight behind the MFMAs
+      const float* As = As2[cur];
+      const float* Bs = Bs2[cur];
       const float4* arow = reinterpret_cast<const float4*>(&As[(wm * 32 + r) * LSK + FH * h]);
       float av[FH], bv[FH];
 #pragma unroll
@@ -264,6 +282,8 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
       for (int u = 0; u < FH; ++u) bv[u] = Bs[(u + FH * h) * LSJ + wn * 32 + r];
 #pragma unroll
       for (int u = 0; u < FH; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+      if (more) store(cur ^ 1);                   // the other buffer: nobody reads it this tile
+      __syncthreads();
     }
   }
 
