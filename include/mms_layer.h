@@ -61,6 +61,35 @@ void mms_caffe_set_random_seed(unsigned seed);
 /* Comma-separated registered layer types ("PairRankLoss,SimCross,SimMatrix"). */
 const char* mms_layer_registry_types(void);
 
+/* ------------------------------------------------------------------------- *
+ * .caffemodel snapshots (binary NetParameter).  Host-only
+ * except the two *_layer functions, which touch Blob memory.
+ * ------------------------------------------------------------------------- */
+typedef struct mms_snapshot mms_snapshot_t;
+typedef struct mms_snapshot_writer mms_snapshot_writer_t;
+
+mms_snapshot_t* mms_snapshot_open(const char* path, char* err, int err_len);
+void mms_snapshot_close(mms_snapshot_t* s);
+const char* mms_snapshot_net_name(const mms_snapshot_t* s);
+int mms_snapshot_num_layers(const mms_snapshot_t* s);
+const char* mms_snapshot_layer_name(const mms_snapshot_t* s, int layer);
+const char* mms_snapshot_layer_type(const mms_snapshot_t* s, int layer);
+int mms_snapshot_num_blobs(const mms_snapshot_t* s, int layer);
+int mms_snapshot_blob_shape(const mms_snapshot_t* s, int layer, int blob, int* shape, int max_axes);
+int mms_snapshot_blob_count(const mms_snapshot_t* s, int layer, int blob);
+const float* mms_snapshot_blob_data(const mms_snapshot_t* s, int layer, int blob);
+/* Net::CopyTrainedLayersFrom for one layer (match by name; 0 ok, 1 name absent,
+ * 2 blob-count mismatch, 3 shape mismatch). */
+int mms_layer_copy_from_snapshot(mms_layer_t* layer, const mms_snapshot_t* s, const char* layer_name);
+
+mms_snapshot_writer_t* mms_snapshot_writer_create(const char* net_name);
+void mms_snapshot_writer_destroy(mms_snapshot_writer_t* w);
+void mms_snapshot_writer_add_layer(mms_snapshot_writer_t* w, const char* name, const char* type);
+void mms_snapshot_writer_add_blob(mms_snapshot_writer_t* w, const int* shape, int num_axes, const float* data);
+/* Layer::ToProto (include/caffe/layer.hpp:506-514). */
+void mms_snapshot_writer_add_from_layer(mms_snapshot_writer_t* w, mms_layer_t* layer, const char* name);
+int mms_snapshot_writer_save(const mms_snapshot_writer_t* w, const char* path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,23 @@ _SIGNATURES = {
     "mms_caffe_set_mode": (None, [_i]),
     "mms_caffe_set_random_seed": (None, [C.c_uint]),
     "mms_layer_registry_types": (C.c_char_p, []),
+    "mms_snapshot_open": (_vp, [C.c_char_p, C.c_char_p, _i]),
+    "mms_snapshot_close": (None, [_vp]),
+    "mms_snapshot_net_name": (C.c_char_p, [_vp]),
+    "mms_snapshot_num_layers": (_i, [_vp]),
+    "mms_snapshot_layer_name": (C.c_char_p, [_vp, _i]),
+    "mms_snapshot_layer_type": (C.c_char_p, [_vp, _i]),
+    "mms_snapshot_num_blobs": (_i, [_vp, _i]),
+    "mms_snapshot_blob_shape": (_i, [_vp, _i, _i, _ip, _i]),
+    "mms_snapshot_blob_count": (_i, [_vp, _i, _i]),
+    "mms_snapshot_blob_data": (_fp, [_vp, _i, _i]),
+    "mms_layer_copy_from_snapshot": (_i, [_vp, _vp, C.c_char_p]),
+    "mms_snapshot_writer_create": (_vp, [C.c_char_p]),
+    "mms_snapshot_writer_destroy": (None, [_vp]),
+    "mms_snapshot_writer_add_layer": (None, [_vp, C.c_char_p, C.c_char_p]),
+    "mms_snapshot_writer_add_blob": (None, [_vp, _ip, _i, _fp]),
+    "mms_snapshot_writer_add_from_layer": (None, [_vp, _vp, C.c_char_p]),
+    "mms_snapshot_writer_save": (_i, [_vp, C.c_char_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -249,3 +266,65 @@ def AUC(**kw):
 
 def RankAccuracy(**kw):
     return _make("RankAccuracy", "rank_accuracy_param", **kw)
+
+
+class Snapshot:
+    """A .caffemodel (binary NetParameter) opened for reading: {layer name: [numpy blobs]}."""
+
+    def __init__(self, path):
+        err = C.create_string_buffer(512)
+        self._h = lib().mms_snapshot_open(str(path).encode(), err, 512)
+        if not self._h:
+            raise IOError(err.value.decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.mms_snapshot_close(self._h)
+            self._h = None
+
+    @property
+    def net_name(self):
+        return lib().mms_snapshot_net_name(self._h).decode()
+
+    def layers(self):
+        out = []
+        for i in range(lib().mms_snapshot_num_layers(self._h)):
+            blobs = []
+            for j in range(lib().mms_snapshot_num_blobs(self._h, i)):
+                shp = (C.c_int * 32)()
+                n = lib().mms_snapshot_blob_shape(self._h, i, j, shp, 32)
+                cnt = lib().mms_snapshot_blob_count(self._h, i, j)
+                data = np.ctypeslib.as_array(lib().mms_snapshot_blob_data(self._h, i, j), shape=(cnt,)).copy() \
+                    if cnt else np.zeros(0, np.float32)
+                blobs.append(data.reshape([shp[a] for a in range(n)]) if n else data)
+            out.append((lib().mms_snapshot_layer_name(self._h, i).decode(),
+                        lib().mms_snapshot_layer_type(self._h, i).decode(), blobs))
+        return out
+
+    def copy_into(self, layer, layer_name):
+        """Net::CopyTrainedLayersFrom for one layer; raises on count / shape mismatch."""
+        rc = lib().mms_layer_copy_from_snapshot(layer._h, self._h, layer_name.encode())
+        if rc == 1:
+            return False
+        if rc:
+            raise ValueError("snapshot layer %r does not fit the target layer (%s)"
+                             % (layer_name, {2: "blob count", 3: "blob shape"}[rc]))
+        return True
+
+
+def save_snapshot(path, net_name, named_layers=(), raw_layers=()):
+    """Write a .caffemodel: `named_layers` = [(name, Layer)], `raw_layers` = [(name, type, [numpy blobs])]."""
+    w = lib().mms_snapshot_writer_create(net_name.encode())
+    try:
+        for name, layer in named_layers:
+            lib().mms_snapshot_writer_add_from_layer(w, layer._h, name.encode())
+        for name, typ, blobs in raw_layers:
+            lib().mms_snapshot_writer_add_layer(w, name.encode(), typ.encode())
+            for b in blobs:
+                b = np.ascontiguousarray(b, np.float32)
+                shp, n = _ints(b.shape)
+                lib().mms_snapshot_writer_add_blob(w, shp, n, b.ctypes.data_as(_fp))
+        if lib().mms_snapshot_writer_save(w, str(path).encode()):
+            raise IOError("cannot write %s" % path)
+    finally:
+        lib().mms_snapshot_writer_destroy(w)
