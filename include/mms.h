@@ -243,6 +243,16 @@ int mms_embed_backward_f32(int M, int N, int K, const float* index, const float*
 
 size_t mms_embed_workspace_bytes(int M, int N);
 
+/* ------------------------------------------------------------------------- *
+ * Batch feed: dst[i,:] = src[perm[first+i],:], i < rows,
+ * for a dataset (src_rows, row_elems) resident in HBM; perm (src_rows ints on
+ * the device) or NULL for the identity; first + rows <= src_rows.
+ * Replaces the per-row caffe_copy loop of HDF5DataLayer<float>::Forward_cpu/_gpu
+ *   src/caffe/layers/hdf5_data_layer.cpp:124-151, hdf5_data_layer.cu:19-51.
+ * ------------------------------------------------------------------------- */
+int mms_feed_gather_rows_f32(int rows, int row_elems, int src_rows, const float* src, const int* perm,
+                             int first, float* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,32 @@ void mms_snapshot_writer_add_blob(mms_snapshot_writer_t* w, const int* shape, in
 void mms_snapshot_writer_add_from_layer(mms_snapshot_writer_t* w, mms_layer_t* layer, const char* name);
 int mms_snapshot_writer_save(const mms_snapshot_writer_t* w, const char* path);
 
+/* ------------------------------------------------------------------------- *
+ * HDF5 batch files, host only.  What the "HDF5Data" layer uses
+ * in place of libhdf5's H5Fopen / H5LTfind_dataset / H5LTget_dataset_info /
+ * H5LTread_dataset_float (src/caffe/util/hdf5.cpp:10-73): root-group datasets of
+ * integer or float type, contiguous / compact / chunked (+deflate, shuffle,
+ * fletcher32), converted to float.  type_class: 0 H5T_INTEGER, 1 H5T_FLOAT.
+ * The writer emits what h5py's `f[name] = ndarray` does for float32 (elem_size 4)
+ * and float64 (8) arrays -- the driver's format, do_trec_qa_clean.py:237-246.
+ * ------------------------------------------------------------------------- */
+typedef struct mms_h5_file mms_h5_file_t;
+typedef struct mms_h5_writer mms_h5_writer_t;
+mms_h5_file_t* mms_h5_open(const char* path, char* err, int err_len);
+void mms_h5_close(mms_h5_file_t* h);
+int mms_h5_num_datasets(const mms_h5_file_t* h);
+const char* mms_h5_dataset_name(const mms_h5_file_t* h, int i);
+/* returns the rank, or -1 with a message in err */
+int mms_h5_dataset_info(const mms_h5_file_t* h, const char* name, long long* dims, int max_axes,
+                        int* type_class, int* elem_size, char* err, int err_len);
+int mms_h5_read_float(const mms_h5_file_t* h, const char* name, float* out, long long capacity,
+                      char* err, int err_len);
+mms_h5_writer_t* mms_h5_writer_create(void);
+void mms_h5_writer_destroy(mms_h5_writer_t* w);
+void mms_h5_writer_add(mms_h5_writer_t* w, const char* name, const long long* dims, int num_axes,
+                       int elem_size, const double* values);
+int mms_h5_writer_save(const mms_h5_writer_t* w, const char* path, char* err, int err_len);
+
 #ifdef __cplusplus
 }
 #endif

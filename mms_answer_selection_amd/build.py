@@ -57,16 +57,17 @@ def build_layers(force=False, verbose=False):
     """C++ mirror of the Caffe Layer/Blob API on top of the C ABI."""
     src = os.path.join(CSRC, "caffe_layers.cpp")
     io_src = os.path.join(CSRC, "caffemodel_io.cpp")
+    h5_src = os.path.join(CSRC, "hdf5_io.cpp")
     if not os.path.exists(src):
         return None
-    deps = [src, io_src, os.path.join(CSRC, "caffe_api.hpp"), os.path.join(ROOT, "include", "mms.h"),
+    deps = [src, io_src, h5_src, os.path.join(CSRC, "hdf5_io.hpp"), os.path.join(CSRC, "caffe_api.hpp"), os.path.join(ROOT, "include", "mms.h"),
             os.path.join(ROOT, "include", "mms_layer.h"), LIB, os.path.abspath(__file__)]
     deps = [d for d in deps if os.path.exists(d)]
     if not force and not _stale(LAYER_LIB, deps):
         return LAYER_LIB
     cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "--offload-arch=gfx950",
-           "-Wall", "-I", os.path.join(ROOT, "include"), "-I", CSRC, src, io_src, "-o", LAYER_LIB,
-           "-L", HERE, "-lmms_hip", "-Wl,-rpath,$ORIGIN"]
+           "-Wall", "-I", os.path.join(ROOT, "include"), "-I", CSRC, src, io_src, h5_src, "-o", LAYER_LIB,
+           "-L", HERE, "-lmms_hip", "-lz", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

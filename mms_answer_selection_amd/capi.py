@@ -37,6 +37,7 @@ _SIGNATURES = {
     "mms_embed_workspace_bytes": (_sz, [_i, _i]),
     "mms_embed_forward_f32": (_i, [_i, _i, _i] + [_vp] * 5),
     "mms_embed_backward_f32": (_i, [_i, _i, _i] + [_vp] * 5 + [_sz, _vp]),
+    "mms_feed_gather_rows_f32": (_i, [_i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "mms_rank_workspace_bytes": (_sz, [_i]),
     "mms_rank_map_mrr_f32": (_i, [_i, _i] + [_vp] * 7 + [_sz, _vp]),
     "mms_rank_auc_f32": (_i, [_i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
@@ -263,3 +264,13 @@ def embed_backward(index, top_diff, weight_diff, bias_diff=None, ws=None):
                                        _ptr(weight_diff, "weight_diff", True),
                                        _ptr(bias_diff, "bias_diff", True), wsp, wsb, _stream()),
           "mms_embed_backward_f32")
+
+
+def feed_gather_rows(src, first, rows, dst, perm=None):
+    """dst[i] = src[perm[first+i]] (perm int32 on the device, or None = identity)."""
+    src_rows = src.shape[0]
+    row_elems = src.numel() // max(src_rows, 1)
+    check(lib().mms_feed_gather_rows_f32(rows, row_elems, src_rows, _ptr(src, "src"),
+                                         _ptr(perm, "perm", True, dtype=torch.int32), first,
+                                         _ptr(dst, "dst"), _stream()),
+          "mms_feed_gather_rows_f32")

@@ -277,6 +277,14 @@ struct AUCParameter {  // caffe.proto:465-469
   bool has_ignore_label() const { return has_ignore_label_; }
   int ignore_label() const { return ignore_label_; }
 };
+struct HDF5DataParameter {  // caffe.proto:827-839
+  string source_;
+  int batch_size_ = 0;
+  bool shuffle_ = false;
+  const string& source() const { return source_; }
+  int batch_size() const { return batch_size_; }
+  bool shuffle() const { return shuffle_; }
+};
 struct ParamSpec {  // caffe.proto:281-308 (subset)
   string name;
   float lr_mult = 1, decay_mult = 1;
@@ -291,6 +299,11 @@ struct LayerParameter {  // caffe.proto:310-416 (subset)
   PairRankLossParameter pair_rank_loss_param_;
   EmbedParameter embed_param_;
   const EmbedParameter& embed_param() const { return embed_param_; }
+  HDF5DataParameter hdf5_data_param_;
+  const HDF5DataParameter& hdf5_data_param() const { return hdf5_data_param_; }
+  bool has_transform_param_ = false;
+  bool has_transform_param() const { return has_transform_param_; }
+  const string& top(int i) const { return top_[i]; }
   MAPParameter map_param_;
   MRRParameter mrr_param_;
   AUCParameter auc_param_;

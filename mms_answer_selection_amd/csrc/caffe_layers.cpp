@@ -12,6 +12,9 @@
 
 #include <cctype>
 
+#include <fstream>
+
+#include "hdf5_io.hpp"
 #include "mms.h"
 #include "mms_layer.h"
 
@@ -608,6 +611,142 @@ class RankAccuracyLayer : public RankMetricLayerBase<Dtype> {
 INSTANTIATE_CLASS(RankAccuracyLayer);
 REGISTER_LAYER_CLASS(RankAccuracy);
 
+// ===================================== HDF5Data ==============================
+// Reference: include/caffe/layers/hdf5_data_layer.hpp, src/caffe/layers/hdf5_data_layer.cpp
+// :27-151 and .cu:19-51.  `source` lists one .h5 file per line; every top is the dataset of
+// the same name, loaded whole and converted to float (util/hdf5.cpp:10-73); a batch is the
+// next batch_size rows, moving on to the next file (and wrapping) when a file is used up,
+// so a batch can straddle two files.  No libhdf5 here: csrc/hdf5_io.cpp decodes the files.
+//
+// MI355X shape of it: the reference keeps the file's blobs on the host and issues batch_size
+// x top_size small copies per Forward (H2D in its GPU path).  Here a file's datasets are
+// uploaded to HBM once, when the file is opened, and a batch is one gather launch per top
+// and per contiguous run of rows (mms_feed_gather_rows_f32): no per-step PCIe traffic.
+//
+// shuffle: the reference uses std::random_shuffle, i.e. libstdc++'s `rand() % (i+1)` swaps
+// driven by the C library's rand() state, which nothing in Caffe seeds.  The same loop and
+// the same rand() are used here, so a process with the same rand() history shuffles alike.
+template <typename Dtype>
+class HDF5DataLayer : public Layer<Dtype> {
+ public:
+  explicit HDF5DataLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  const char* type() const override { return "HDF5Data"; }
+  int ExactNumBottomBlobs() const override { return 0; }
+  int MinTopBlobs() const override { return 1; }
+
+  void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    CHECK(!this->layer_param_.has_transform_param()) << this->type() << " does not transform data.";
+    const string& source = this->layer_param_.hdf5_data_param().source();
+    LOG_INFO << "Loading list of HDF5 filenames from: " << source;
+    hdf_filenames_.clear();
+    std::ifstream source_file(source.c_str());
+    CHECK(source_file.is_open()) << "Failed to open source file: " << source;
+    string line;
+    while (source_file >> line) hdf_filenames_.push_back(line);
+    source_file.close();
+    num_files_ = (int)hdf_filenames_.size();
+    current_file_ = 0;
+    CHECK_GE(num_files_, 1) << "Must have at least 1 HDF5 filename listed in " << source;
+    file_permutation_.resize(num_files_);
+    for (int i = 0; i < num_files_; ++i) file_permutation_[i] = i;
+    if (this->layer_param_.hdf5_data_param().shuffle()) RandomShuffle(&file_permutation_);
+    LoadHDF5FileData(hdf_filenames_[file_permutation_[current_file_]].c_str());
+    current_row_ = 0;
+    const int batch_size = this->layer_param_.hdf5_data_param().batch_size();
+    for (size_t i = 0; i < top.size(); ++i) {
+      vector<int> top_shape = hdf_blobs_[i]->shape();
+      top_shape[0] = batch_size;
+      top[i]->Reshape(top_shape);
+    }
+  }
+  void Reshape(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) override {}
+
+ protected:
+  // libstdc++'s std::random_shuffle(first, last) (removed in C++17), spelled out.
+  static void RandomShuffle(vector<int>* v) {
+    for (size_t i = 1; i < v->size(); ++i) {
+      const size_t j = (size_t)std::rand() % (i + 1);
+      if (i != j) std::swap((*v)[i], (*v)[j]);
+    }
+  }
+  void UploadPermutation() {
+    const int n = (int)data_permutation_.size();
+    perm_mem_.reset(new SyncedMemory((size_t)n * sizeof(int)));
+    std::memcpy(perm_mem_->mutable_cpu_data(), data_permutation_.data(), (size_t)n * sizeof(int));
+  }
+  void LoadHDF5FileData(const char* filename) {
+    mms_h5::File file;
+    string err;
+    CHECK(file.Open(filename, &err)) << err;
+    const int top_size = this->layer_param_.top_size();
+    hdf_blobs_.resize(top_size);
+    for (int i = 0; i < top_size; ++i) {
+      const string& name = this->layer_param_.top(i);
+      CHECK(file.Find(name)) << "Failed to find HDF5 dataset " << name;
+      mms_h5::DatasetInfo info;
+      std::vector<float> values;
+      CHECK(file.ReadFloat(name, &info, &values, &err)) << "Failed to read float dataset " << name << ": " << err;
+      CHECK_GE((int)info.dims.size(), 1) << "Input must have at least 1 axis.";
+      vector<int> shape;
+      for (int64_t d : info.dims) shape.push_back((int)d);
+      hdf_blobs_[i].reset(new Blob<Dtype>(shape));
+      std::memcpy(hdf_blobs_[i]->mutable_cpu_data(), values.data(), values.size() * sizeof(float));
+    }
+    const int num = hdf_blobs_[0]->shape(0);
+    for (int i = 1; i < top_size; ++i) CHECK_EQ(hdf_blobs_[i]->shape(0), num);
+    data_permutation_.resize(num);
+    for (int i = 0; i < num; ++i) data_permutation_[i] = i;
+    if (this->layer_param_.hdf5_data_param().shuffle()) RandomShuffle(&data_permutation_);
+    UploadPermutation();
+  }
+  void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
+  void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) override {}
+  void Backward_gpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) override {}
+
+  // Same row/file walk as hdf5_data_layer.cpp:124-151, taken a run of rows at a time.
+  void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    const int batch_size = this->layer_param_.hdf5_data_param().batch_size();
+    const bool shuffle = this->layer_param_.hdf5_data_param().shuffle();
+    int i = 0;
+    while (i < batch_size) {
+      if (current_row_ == hdf_blobs_[0]->shape(0)) {
+        if (num_files_ > 1) {
+          ++current_file_;
+          if (current_file_ == num_files_) {
+            current_file_ = 0;
+            if (shuffle) RandomShuffle(&file_permutation_);
+          }
+          // launches reading the old file's buffers are on the null stream; hipFree in
+          // ~SyncedMemory synchronises with them before the memory goes away
+          LoadHDF5FileData(hdf_filenames_[file_permutation_[current_file_]].c_str());
+        }
+        current_row_ = 0;
+        if (shuffle) { RandomShuffle(&data_permutation_); HIP_CHECK(hipDeviceSynchronize()); UploadPermutation(); }
+      }
+      const int rows = hdf_blobs_[0]->shape(0);
+      CHECK_GT(rows, 0) << "HDF5 file with no rows";
+      const int run = std::min(batch_size - i, rows - current_row_);
+      for (size_t j = 0; j < top.size(); ++j) {
+        const int data_dim = top[j]->count() / top[j]->shape(0);
+        mms_check(mms_feed_gather_rows_f32(run, data_dim, rows, hdf_blobs_[j]->gpu_data(),
+                                           shuffle ? static_cast<const int*>(perm_mem_->gpu_data()) : nullptr,
+                                           current_row_, top[j]->mutable_gpu_data() + (size_t)i * data_dim, nullptr),
+                  "mms_feed_gather_rows_f32");
+      }
+      i += run;
+      current_row_ += run;
+    }
+  }
+
+  vector<string> hdf_filenames_;
+  int num_files_ = 0, current_file_ = 0, current_row_ = 0;
+  vector<shared_ptr<Blob<Dtype> > > hdf_blobs_;
+  vector<int> data_permutation_, file_permutation_;
+  std::unique_ptr<SyncedMemory> perm_mem_;
+};
+INSTANTIATE_CLASS(HDF5DataLayer);
+REGISTER_LAYER_CLASS(HDF5Data);
+
 // ============================ prototxt (text format) subset ==================
 namespace {
 struct Tok {
@@ -788,6 +927,18 @@ class Parser {
         return false;
       });
     }
+    if (n == "hdf5_data_param") {
+      HDF5DataParameter* p = &lp->hdf5_data_param_;
+      return message([&](const string& m) {
+        Tok w;
+        if (!scalar(&w)) return false;
+        if (m == "source") { p->source_ = w.text; return true; }
+        if (m == "batch_size") return as_int(w, &p->batch_size_);
+        if (m == "shuffle") return as_bool(w, &p->shuffle_);
+        return false;
+      });
+    }
+    if (n == "transform_param") { lp->has_transform_param_ = true; return skip_value(); }
     if (n == "map_param" || n == "mrr_param") {
       int* fa = n == "map_param" ? &lp->map_param_.fixed_axis_ : &lp->mrr_param_.fixed_axis_;
       return message([&](const string& m) {
@@ -926,6 +1077,60 @@ const char* mms_layer_registry_types(void) {
   s.clear();
   for (auto& t : caffe::LayerRegistry<float>::LayerTypeList()) s += (s.empty() ? "" : ",") + t;
   return s.c_str();
+}
+
+// ---- HDF5 files (host only) ----
+struct mms_h5_file { mms_h5::File f; std::vector<std::string> names; };
+static void set_err(char* err, int err_len, const std::string& m) {
+  if (err && err_len > 0) std::snprintf(err, err_len, "%s", m.c_str());
+}
+mms_h5_file_t* mms_h5_open(const char* path, char* err, int err_len) {
+  std::unique_ptr<mms_h5_file> h(new mms_h5_file);
+  std::string e;
+  if (!path || !h->f.Open(path, &e)) { set_err(err, err_len, e.empty() ? "null path" : e); return nullptr; }
+  h->names = h->f.DatasetNames();
+  return h.release();
+}
+void mms_h5_close(mms_h5_file_t* h) { delete h; }
+int mms_h5_num_datasets(const mms_h5_file_t* h) { return (int)h->names.size(); }
+const char* mms_h5_dataset_name(const mms_h5_file_t* h, int i) { return h->names[i].c_str(); }
+int mms_h5_dataset_info(const mms_h5_file_t* h, const char* name, long long* dims, int max_axes,
+                        int* type_class, int* elem_size, char* err, int err_len) {
+  mms_h5::DatasetInfo info;
+  std::string e;
+  if (!h->f.Info(name, &info, &e)) { set_err(err, err_len, e); return -1; }
+  for (int a = 0; a < (int)info.dims.size() && a < max_axes; ++a) dims[a] = info.dims[a];
+  if (type_class) *type_class = info.type_class;
+  if (elem_size) *elem_size = info.elem_size;
+  return (int)info.dims.size();
+}
+int mms_h5_read_float(const mms_h5_file_t* h, const char* name, float* out, long long capacity,
+                      char* err, int err_len) {
+  mms_h5::DatasetInfo info;
+  std::vector<float> v;
+  std::string e;
+  if (!h->f.ReadFloat(name, &info, &v, &e)) { set_err(err, err_len, e); return 1; }
+  if ((long long)v.size() > capacity) { set_err(err, err_len, "output buffer too small"); return 2; }
+  std::memcpy(out, v.data(), v.size() * sizeof(float));
+  return 0;
+}
+struct mms_h5_writer { std::vector<mms_h5::WriteDataset> sets; };
+mms_h5_writer_t* mms_h5_writer_create(void) { return new mms_h5_writer; }
+void mms_h5_writer_destroy(mms_h5_writer_t* w) { delete w; }
+void mms_h5_writer_add(mms_h5_writer_t* w, const char* name, const long long* dims, int num_axes,
+                       int elem_size, const double* values) {
+  mms_h5::WriteDataset d;
+  d.name = name;
+  d.elem_size = elem_size;
+  long long c = 1;
+  for (int a = 0; a < num_axes; ++a) { d.dims.push_back(dims[a]); c *= dims[a]; }
+  d.values.assign(values, values + c);
+  w->sets.push_back(std::move(d));
+}
+int mms_h5_writer_save(const mms_h5_writer_t* w, const char* path, char* err, int err_len) {
+  std::string e;
+  if (!mms_h5::WriteContiguous(path, w->sets, &e)) { set_err(err, err_len, e); return 1; }
+  return 0;
 }
 
 }  // extern "C"

@@ -14,6 +14,7 @@
 //             CPU code, no atomics.  The zero-pad word id owns thousands of rows
 //             in a TREC-QA batch; its chain is long (one dependent add per row
 //             per column) but is a single destination among ~10^3 short ones.
+#include <algorithm>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -143,6 +144,33 @@ int embed_backward(int M, int N, int K, const float* index, const float* top_dif
     hipLaunchKernelGGL(embed_bias_finish_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s,
                        lay.chunks, N, partial, bias_diff);
   }
+  return launch_status();
+}
+
+// ---- batch feed: rows of a device-resident dataset -> one top blob -----------------
+// Replaces the per-row caffe_copy loop of HDF5DataLayer::Forward_cpu/_gpu
+// (src/caffe/layers/hdf5_data_layer.cpp:124-151, hdf5_data_layer.cu:19-51): the whole
+// file's dataset lives in HBM, a batch is ONE launch gathering `rows` rows through the
+// layer's row permutation (identity unless hdf5_data_param.shuffle).
+__global__ __launch_bounds__(256) void feed_gather_kernel(int rows, int row_elems, int src_rows,
+                                                          const float* __restrict__ src,
+                                                          const int* __restrict__ perm, int first,
+                                                          float* __restrict__ dst) {
+  const size_t total = (size_t)rows * row_elems;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int i = (int)(e / row_elems), d = (int)(e - (size_t)i * row_elems);
+    int r = perm ? perm[first + i] : first + i;
+    r = r < 0 ? 0 : (r >= src_rows ? src_rows - 1 : r);
+    dst[e] = src[(size_t)r * row_elems + d];
+  }
+}
+
+int feed_gather_rows(int rows, int row_elems, int src_rows, const float* src, const int* perm, int first,
+                     float* dst, hipStream_t s) {
+  const size_t total = (size_t)rows * row_elems;
+  const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(feed_gather_kernel, dim3(blocks), dim3(256), 0, s, rows, row_elems, src_rows, src, perm,
+                     first, dst);
   return launch_status();
 }
 

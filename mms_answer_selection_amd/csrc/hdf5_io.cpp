@@ -16,6 +16,7 @@ namespace {
 const uint8_t kSignature[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
 const uint64_t kUndef = ~0ull;
 const int kMaxDepth = 32;
+const uint64_t kMaxNodes = 1u << 20;
 
 bool fail(std::string* err, const std::string& m) {
   if (err) *err = m;
@@ -98,7 +99,7 @@ bool File::Open(const std::string& path, std::string* err) {
 
 // III.A.1 version-1 B-tree, node type 0 (group nodes); leaves point at SNODs (III.B).
 bool File::WalkGroupTree(uint64_t node, uint64_t heap_data, int depth, std::string* err) {
-  if (depth > kMaxDepth) return fail(err, "group B-tree too deep");
+  if (depth > kMaxDepth || ++nodes_visited_ > kMaxNodes) return fail(err, "group B-tree too deep or cyclic");
   if (!In(node, 24)) return fail(err, "group node outside the file");
   if (!std::memcmp(buf_.data() + node, "SNOD", 4)) {
     const int nsym = (int)U(node + 6, 2);
@@ -240,6 +241,16 @@ bool File::ParseObject(uint64_t addr, Parsed* p, std::string* err) const {
     }
   }
   if (!p->have_space || !p->have_type || !p->have_layout) return fail(err, "object is not a simple dataset");
+  // Plausibility: a Blob counts elements in an int (blob.cpp Reshape CHECK_LE(shape[i], INT_MAX / count_)),
+  // uncompressed data cannot be larger than the file and deflate expands at most ~1032x.
+  uint64_t count = 1;
+  for (int64_t d : p->info.dims) {
+    if (d < 0 || (d > 0 && count > 0x7fffffffull / (uint64_t)d)) return fail(err, "blob size exceeds INT_MAX");
+    count *= (uint64_t)d;
+  }
+  const uint64_t bytes = count * (uint64_t)p->info.elem_size;
+  const uint64_t limit = p->layout_class == 2 && !p->filters.empty() ? buf_.size() * 1100ull : buf_.size();
+  if (bytes > limit) return fail(err, "dataset larger than its file can hold");
   return true;
 }
 
@@ -287,7 +298,7 @@ bool apply_filters_reverse(const std::vector<Filter>& filters, uint32_t mask, in
 
 // III.A.1 version-1 B-tree, node type 1 (raw data chunks).
 bool File::WalkChunkTree(uint64_t node, const Parsed& p, std::vector<uint8_t>* raw, int depth, std::string* err) const {
-  if (depth > kMaxDepth) return fail(err, "chunk B-tree too deep");
+  if (depth > kMaxDepth || ++nodes_visited_ > kMaxNodes) return fail(err, "chunk B-tree too deep or cyclic");
   if (!In(node, 24) || std::memcmp(buf_.data() + node, "TREE", 4) || buf_[node + 4] != 1)
     return fail(err, "bad chunk B-tree node");
   const int level = buf_[node + 5], nent = (int)U(node + 6, 2);
@@ -349,7 +360,14 @@ bool File::ReadRaw(const Parsed& p, std::vector<uint8_t>* raw, std::string* err)
     std::memcpy(raw->data(), buf_.data() + base_ + p.data_addr, bytes);
   } else {
     if (p.chunk_dims.size() != p.info.dims.size()) return fail(err, "chunk rank differs from dataset rank");
-    for (uint64_t c : p.chunk_dims) if (c == 0) return fail(err, "zero chunk dimension");
+    uint64_t chunk_bytes = (uint64_t)p.info.elem_size;
+    for (uint64_t c : p.chunk_dims) {
+      if (c == 0) return fail(err, "zero chunk dimension");
+      if (chunk_bytes > 0x7fffffffull / c) return fail(err, "implausible chunk size");
+      chunk_bytes *= c;
+    }
+    if (chunk_bytes > buf_.size() * 1100ull) return fail(err, "chunk larger than its file can hold");
+    nodes_visited_ = 0;
     if (p.chunk_btree == kUndef) return true;
     return WalkChunkTree(base_ + p.chunk_btree, p, raw, 0, err);
   }

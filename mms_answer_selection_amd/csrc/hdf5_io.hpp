@@ -52,6 +52,7 @@ class File {
   uint64_t U(uint64_t off, int bytes) const;
   std::vector<uint8_t> buf_;
   uint64_t base_ = 0;
+  mutable uint64_t nodes_visited_ = 0;        // guards against cyclic B-trees in damaged files
   std::map<std::string, uint64_t> objects_;   // dataset name -> object header address
 };
 

@@ -58,6 +58,8 @@ int embed_forward(int M, int N, int K, const float* index, const float* weight, 
                   float* top, hipStream_t s);
 int embed_backward(int M, int N, int K, const float* index, const float* top_diff,
                    float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes, hipStream_t s);
+int feed_gather_rows(int rows, int row_elems, int src_rows, const float* src, const int* perm, int first,
+                     float* dst, hipStream_t s);
 }  // namespace mms
 
 using namespace mms;
@@ -295,6 +297,15 @@ int mms_embed_backward_f32(int M, int N, int K, const float* index, const float*
   if (!index || !top_diff) return MMS_ERR_INVALID_ARG;
   return embed_backward(M, N, K, index, top_diff, weight_diff, bias_diff, workspace, workspace_bytes,
                         as_stream(stream));
+}
+
+int mms_feed_gather_rows_f32(int rows, int row_elems, int src_rows, const float* src, const int* perm,
+                             int first, float* dst, void* stream) {
+  if (rows < 0 || row_elems <= 0 || src_rows <= 0 || first < 0) return MMS_ERR_INVALID_ARG;
+  if ((long long)rows * row_elems > 0x7fffffffLL || (long long)first + rows > src_rows) return MMS_ERR_INVALID_ARG;
+  if (rows == 0) return MMS_OK;
+  if (!src || !dst) return MMS_ERR_INVALID_ARG;
+  return feed_gather_rows(rows, row_elems, src_rows, src, perm, first, dst, as_stream(stream));
 }
 
 }  // extern "C"

@@ -45,6 +45,16 @@ _SIGNATURES = {
     "mms_caffe_set_mode": (None, [_i]),
     "mms_caffe_set_random_seed": (None, [C.c_uint]),
     "mms_layer_registry_types": (C.c_char_p, []),
+    "mms_h5_open": (_vp, [C.c_char_p, C.c_char_p, _i]),
+    "mms_h5_close": (None, [_vp]),
+    "mms_h5_num_datasets": (_i, [_vp]),
+    "mms_h5_dataset_name": (C.c_char_p, [_vp, _i]),
+    "mms_h5_dataset_info": (_i, [_vp, C.c_char_p, C.POINTER(C.c_longlong), _i, _ip, _ip, C.c_char_p, _i]),
+    "mms_h5_read_float": (_i, [_vp, C.c_char_p, _fp, C.c_longlong, C.c_char_p, _i]),
+    "mms_h5_writer_create": (_vp, []),
+    "mms_h5_writer_destroy": (None, [_vp]),
+    "mms_h5_writer_add": (None, [_vp, C.c_char_p, C.POINTER(C.c_longlong), _i, _i, C.POINTER(C.c_double)]),
+    "mms_h5_writer_save": (_i, [_vp, C.c_char_p, C.c_char_p, _i]),
     "mms_snapshot_open": (_vp, [C.c_char_p, C.c_char_p, _i]),
     "mms_snapshot_close": (None, [_vp]),
     "mms_snapshot_net_name": (C.c_char_p, [_vp]),
@@ -222,8 +232,10 @@ class Layer:
         lib().mms_layer_set_param_propagate_down(self._h, int(i), 1 if v else 0)
 
 
-def _make(type_name, param_field, name=None, loss_weight=None, **kwargs):
+def _make(type_name, param_field, name=None, loss_weight=None, top=None, **kwargs):
     d = {"name": name or type_name.lower(), "type": type_name}
+    if top is not None:
+        d["top"] = list(top)
     if loss_weight is not None:
         d["loss_weight"] = loss_weight
     if kwargs:
@@ -249,6 +261,15 @@ def Embed(**kw):
     """L.Embed(question, input_dim=V, num_output=Dw, weight_filler=..., weight_source=...)
     (do_trec_qa_clean.py:461-466)."""
     return _make("Embed", "embed_param", **kw)
+
+
+def HDF5Data(top, **kw):
+    """L.HDF5Data(batch_size=B, source=list_file, shuffle=0, ntop=5) with the tops named after the
+    datasets, as NetSpec names them from the assignment targets (do_trec_qa_clean.py:380)."""
+    kw.pop("ntop", None)
+    if "shuffle" in kw:
+        kw["shuffle"] = bool(kw["shuffle"])
+    return _make("HDF5Data", "hdf5_data_param", top=top, **kw)
 
 
 def MAP(**kw):
@@ -328,3 +349,56 @@ def save_snapshot(path, net_name, named_layers=(), raw_layers=()):
             raise IOError("cannot write %s" % path)
     finally:
         lib().mms_snapshot_writer_destroy(w)
+
+
+class H5File:
+    """An HDF5 file as the HDF5Data layer sees it: root-group datasets, read whole as float32."""
+
+    def __init__(self, path):
+        err = C.create_string_buffer(512)
+        self._h = lib().mms_h5_open(str(path).encode(), err, 512)
+        if not self._h:
+            raise IOError(err.value.decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.mms_h5_close(self._h)
+            self._h = None
+
+    def keys(self):
+        return [lib().mms_h5_dataset_name(self._h, i).decode() for i in range(lib().mms_h5_num_datasets(self._h))]
+
+    def info(self, name):
+        """-> (shape, type_class 0 int / 1 float, element bytes)"""
+        dims = (C.c_longlong * 32)()
+        cls, es = C.c_int(), C.c_int()
+        err = C.create_string_buffer(512)
+        n = lib().mms_h5_dataset_info(self._h, name.encode(), dims, 32, C.byref(cls), C.byref(es), err, 512)
+        if n < 0:
+            raise KeyError(err.value.decode())
+        return tuple(dims[a] for a in range(n)), cls.value, es.value
+
+    def __getitem__(self, name):
+        shape, _, _ = self.info(name)
+        out = np.empty(shape, np.float32)
+        err = C.create_string_buffer(512)
+        if lib().mms_h5_read_float(self._h, name.encode(), out.ctypes.data_as(_fp), out.size, err, 512):
+            raise IOError(err.value.decode())
+        return out
+
+
+def write_h5(path, datasets):
+    """{name: float32 / float64 ndarray} -> contiguous root-group datasets (what h5py's `f[name] = arr` writes)."""
+    w = lib().mms_h5_writer_create()
+    try:
+        for name, arr in datasets.items():
+            arr = np.asarray(arr)
+            es = 4 if arr.dtype == np.float32 else 8
+            vals = np.ascontiguousarray(arr, np.float64)
+            dims = (C.c_longlong * max(1, arr.ndim))(*arr.shape)
+            lib().mms_h5_writer_add(w, name.encode(), dims, arr.ndim, es, vals.ctypes.data_as(C.POINTER(C.c_double)))
+        err = C.create_string_buffer(512)
+        if lib().mms_h5_writer_save(w, str(path).encode(), err, 512):
+            raise IOError(err.value.decode())
+    finally:
+        lib().mms_h5_writer_destroy(w)

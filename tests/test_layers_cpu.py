@@ -28,7 +28,7 @@ def test_header_symbols_exported(L):
 
 def test_registry_has_reference_type_strings(L):
     # sim_cross_layer.hpp:22, sim_matrix_layer.hpp:22, pair_rank_loss_layer.hpp:24
-    assert sorted(L.registered_layer_types()) == ["AUC", "Embed", "MAP", "MRR", "PairRankLoss", "RankAccuracy",
+    assert sorted(L.registered_layer_types()) == ["AUC", "Embed", "HDF5Data", "MAP", "MRR", "PairRankLoss", "RankAccuracy",
                                                   "SimCross", "SimMatrix"]
 
 

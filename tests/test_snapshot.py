@@ -141,6 +141,25 @@ def test_malformed_and_missing(tmp_path):
     assert L.Snapshot(p).layers() == []
 
 
+def test_mutated_snapshots_never_crash(tmp_path):
+    r = np.random.default_rng(9)
+    net, _ = _ref_net(r)
+    raw = net.SerializeToString()
+    p = tmp_path / "fz.caffemodel"
+    for trial in range(300):
+        b = bytearray(raw)
+        if trial % 2:
+            b = b[: int(r.integers(0, len(b)))]
+        else:
+            for _ in range(int(r.integers(1, 8))):
+                b[int(r.integers(0, len(b)))] = int(r.integers(0, 256))
+        p.write_bytes(bytes(b))
+        try:
+            L.Snapshot(p).layers()
+        except (IOError, ValueError, UnicodeDecodeError):
+            pass
+
+
 @pytest.mark.gpu
 def test_copy_trained_layers_into_simcross_and_back(tmp_path):
     """Net::CopyTrainedLayersFrom semantics on a live SimCross layer, then Layer::ToProto back out."""
