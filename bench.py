@@ -45,7 +45,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=4096)
     p.add_argument("--warmup", type=int, default=256)
-    p.add_argument("--group", type=int, default=16, help="steps per hipGraph / all-gather bucket")
+    p.add_argument("--group", type=int, default=64, help="steps per hipGraph / all-gather bucket")
     p.add_argument("--ring", type=int, default=64, help="distinct batches walked (HBM-cold)")
     p.add_argument("--warm", action="store_true", help="re-use one batch (Infinity-Cache-warm)")
     p.add_argument("--path", choices=["fused", "layers", "triplet"], default="fused",
@@ -240,6 +240,12 @@ def run(args):
             dist.barrier()
             torch.cuda.synchronize()
 
+    if world > 1:
+        # communicator set-up (lazy on the first collective) must not land in the timed region even
+        # when --warmup is 0: one untimed all-gather per bucket
+        gather_bucket(0)
+        gather_bucket(1)
+        fence()
     g0 = run_steps(args.warmup, 0)
     fence()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
