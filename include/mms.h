@@ -50,6 +50,23 @@ int mms_version(void);
 const char* mms_error_string(int code);
 
 /* ------------------------------------------------------------------------- *
+ * Arithmetic of the Euclidean backward term  tt = dT*T*T*T*(q-a)/(T-1+1e-9)
+ * (sim_cross_layer.cpp:214-216: float products divided by a DOUBLE, rounded once
+ * to float).  The forward value T is bit-identical to the CPU code in both modes.
+ *   MMS_EUCLID_BWD_FP32 (default): fp32 throughout, tt = (c*(q-a)) * fl32(1/den);
+ *       at most 2 ulp from the reference's value (<= 1.2e-7 relative; the bar is
+ *       1e-5).  Used by the kernels specialised for D = 100 / 200 / 300 in the
+ *       one-word geometry; every other kernel always runs the reference mode.
+ *   MMS_EUCLID_BWD_REFERENCE: the reference's bits, everywhere.
+ * Process-wide; may also be chosen with the environment variable
+ * MMS_EUCLID_BWD=reference|fp32 read at the first Euclidean launch.
+ * ------------------------------------------------------------------------- */
+#define MMS_EUCLID_BWD_FP32 0
+#define MMS_EUCLID_BWD_REFERENCE 1
+int mms_set_euclid_backward_mode(int mode);
+int mms_get_euclid_backward_mode(void);
+
+/* ------------------------------------------------------------------------- *
  * SimCross  (q (N,W1,D), a (N,W2,D) -> top (N, M|1, W1, W2))
  * ------------------------------------------------------------------------- */
 

@@ -5,6 +5,9 @@ hipcc cross-compiles without a GPU.  Flags that matter for parity:
                       add must round separately for bit-exact Euclidean paths.
   -fhip-fp32-correctly-rounded-divide-sqrt   IEEE sqrt / divide (hipcc default,
                       stated explicitly because the parity tests rely on it).
+  -mllvm -amdgpu-kernarg-preload-count=16   leading kernel arguments are placed in
+                      SGPRs at wave launch (gfx940+), so a latency-bound kernel does not
+                      begin with a scalar fetch of its argument block.
 """
 import os
 import shutil
@@ -23,6 +26,7 @@ HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-fno-fast-math", "-Wall", "-Wno-unused-function",
+    "-mllvm", "-amdgpu-kernarg-preload-count=16",
 ]
 
 

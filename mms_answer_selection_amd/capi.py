@@ -38,6 +38,8 @@ _SIGNATURES = {
     "mms_embed_forward_f32": (_i, [_i, _i, _i] + [_vp] * 5),
     "mms_embed_backward_f32": (_i, [_i, _i, _i] + [_vp] * 5 + [_sz, _vp]),
     "mms_feed_gather_rows_f32": (_i, [_i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "mms_set_euclid_backward_mode": (_i, [_i]),
+    "mms_get_euclid_backward_mode": (_i, []),
     "mms_rank_workspace_bytes": (_sz, [_i]),
     "mms_rank_map_mrr_f32": (_i, [_i, _i] + [_vp] * 7 + [_sz, _vp]),
     "mms_rank_auc_f32": (_i, [_i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
@@ -274,3 +276,16 @@ def feed_gather_rows(src, first, rows, dst, perm=None):
                                          _ptr(perm, "perm", True, dtype=torch.int32), first,
                                          _ptr(dst, "dst"), _stream()),
           "mms_feed_gather_rows_f32")
+
+
+EUCLID_BWD_FP32, EUCLID_BWD_REFERENCE = 0, 1
+
+
+def set_euclid_backward_mode(mode):
+    """'fp32' (default: <= 2 ulp from the reference) or 'reference' (the reference's bits)."""
+    m = {"fp32": 0, "reference": 1}.get(mode, mode)
+    check(lib().mms_set_euclid_backward_mode(int(m)), "mms_set_euclid_backward_mode")
+
+
+def get_euclid_backward_mode():
+    return "reference" if lib().mms_get_euclid_backward_mode() == 1 else "fp32"

@@ -58,6 +58,8 @@ int embed_forward(int M, int N, int K, const float* index, const float* weight, 
                   float* top, hipStream_t s);
 int embed_backward(int M, int N, int K, const float* index, const float* top_diff,
                    float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes, hipStream_t s);
+int euclid_backward_mode();
+void set_euclid_backward_mode(int m);
 int feed_gather_rows(int rows, int row_elems, int src_rows, const float* src, const int* perm, int first,
                      float* dst, hipStream_t s);
 }  // namespace mms
@@ -307,5 +309,12 @@ int mms_feed_gather_rows_f32(int rows, int row_elems, int src_rows, const float*
   if (!src || !dst) return MMS_ERR_INVALID_ARG;
   return feed_gather_rows(rows, row_elems, src_rows, src, perm, first, dst, as_stream(stream));
 }
+
+int mms_set_euclid_backward_mode(int mode) {
+  if (mode != MMS_EUCLID_BWD_FP32 && mode != MMS_EUCLID_BWD_REFERENCE) return MMS_ERR_INVALID_ARG;
+  set_euclid_backward_mode(mode);
+  return MMS_OK;
+}
+int mms_get_euclid_backward_mode(void) { return euclid_backward_mode(); }
 
 }  // extern "C"

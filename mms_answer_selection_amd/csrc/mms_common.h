@@ -40,6 +40,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Sum across each 32-lane HALF of a wave (lanes 0-31 and 32-63 separately); every
+// lane ends with its half's total.  Four DPP steps give each row of 16 its total;
+// gfx950's v_permlane16_swap then exchanges odd and even rows so that one more add
+// completes both halves at once.
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v = dpp_add<0xB1, 0xf>(v);
+  v = dpp_add<0x4E, 0xf>(v);
+  v = dpp_add<0x141, 0xf>(v);
+  v = dpp_add<0x140, 0xf>(v);
+  const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+
 // Sum across a workgroup of THREADS (multiple of 64) threads; result valid in
 // every thread.  `red` is LDS scratch of THREADS/64 floats.  Fixed order.
 template <int THREADS>

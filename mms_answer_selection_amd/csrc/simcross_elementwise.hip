@@ -21,6 +21,10 @@
 //
 // Compiled with -ffp-contract=off: the reference CPU build has no FMA
 // contraction, so mul and add must round separately to match it bitwise.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
 #include "euclid_math.h"
 #include "mms_common.h"
 
@@ -198,6 +202,141 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
     o1.x = 0.f + (-t[it].x); o1.y = 0.f + (-t[it].y); o1.z = 0.f + (-t[it].z); o1.w = 0.f + (-t[it].w);
     dq4[i] = o0;
     da4[i] = o1;
+  }
+  MMS_STAMP(6);
+#ifdef MMS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MMS_STAMP(7);
+}
+
+// ---- width-specialised wave-pair kernel (the headline configuration) ----------
+// Same algorithm as euclid_rows_wave_kernel<.., RW = 2, ..> for D/4 = D4C known at
+// compile time, with the layout made ROW-ALIGNED: lanes 0-31 own pair 2w, lanes
+// 32-63 pair 2w+1, lane j holds float4s j, j+32, j+64 of its pair.  A lane then
+// belongs to ONE pair for everything it does (loads, squares, speculation lane,
+// coefficients, stores): no per-slot pair masks, no cross-lane broadcast of the
+// coefficients, half-wave DPP sums, and every loop bound is a constant, so the
+// chain is straight-line code.  About 40 % fewer wave-instructions than the
+// generic kernel, which is what bounds this kernel.
+//
+// EXACT selects the arithmetic of the backward term tt = dT*T^3*(q-a)/(T-1+1e-9):
+//   true : the reference's bits (fp32 product, DOUBLE divisor, one rounding to
+//          float) through the checked reciprocal fast path of euclid_math.h;
+//   false: fp32 throughout, tt = (c*(q-a)) * fl32(1/den): at most 2 ulp from the
+//          reference's value (1.2e-7 relative against the 1e-5 bar), a third of
+//          the instructions.  The FORWARD value T is bit-exact in both.
+template <int D4C, bool FWD, bool BWD, bool EXACT>
+__global__ __launch_bounds__(256) void euclid_pair32_kernel(
+    int N, const float* __restrict__ q, const float* __restrict__ a,
+    const float* __restrict__ top_in, const float* __restrict__ top_diff,
+    float* __restrict__ top_out, float* __restrict__ dq, float* __restrict__ da) {
+  // N first: with -amdgpu-kernarg-preload-count the leading arguments arrive in SGPRs at wave
+  // start, so the loads below do not wait on a scalar fetch of the argument block
+  constexpr int NIT = (D4C + 31) / 32;
+  constexpr int LASTN = D4C - 32 * (NIT - 1);    // lanes with a float4 in the last slot
+  constexpr int H4 = (D4C + 2) / 3, ST4 = 3 * H4;
+  __shared__ float4 lds4[FWD ? 4 * 2 * ST4 : 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = lane >> 5, j = lane & 31;
+  // No early exit: a wave past the end works on the last pair and stores nothing, so that no
+  // branch (and no wait on the kernel arguments) stands between wave start and the loads.
+  const int want = (blockIdx.x * 4 + wave) * 2 + grp;
+  const bool have = want < N;
+  const int row = have ? want : N - 1;
+  const float4* q4 = reinterpret_cast<const float4*>(q) + (size_t)row * D4C;
+  const float4* a4 = reinterpret_cast<const float4*>(a) + (size_t)row * D4C;
+  const bool last_ok = (LASTN >= 32) || (j < LASTN);
+
+  MMS_STAMP(0);
+  float4 x[NIT], y[NIT], df[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = (it < NIT - 1 || last_ok) ? j + 32 * it : 0;   // clamp: keep the load unconditional
+    x[it] = q4[i];
+    y[it] = a4[i];
+  }
+  MMS_STAMP(1);
+  float T = 0.f;
+  if (!FWD) T = top_in[row];
+  float g = 0.f;
+  if (BWD) g = top_diff[row];
+
+  float p1 = 0.f, p2 = 0.f;
+  float4* img = lds4 + (wave * 2 + grp) * ST4;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    df[it].x = x[it].x - y[it].x; df[it].y = x[it].y - y[it].y;
+    df[it].z = x[it].z - y[it].z; df[it].w = x[it].w - y[it].w;
+    if (FWD) {
+      const bool valid = (it < NIT - 1) || last_ok;
+      float4 s;
+      s.x = df[it].x * df[it].x; s.y = df[it].y * df[it].y;
+      s.z = df[it].z * df[it].z; s.w = df[it].w * df[it].w;
+      if (valid) img[j + 32 * it] = s;
+      const float s4 = valid ? (s.x + s.y) + (s.z + s.w) : 0.f;
+      const int i = j + 32 * it;
+      // tree-sum contributions to the two window centres (segment 0; segments 0-1)
+      if (32 * it + 31 < H4) p1 += s4;
+      else if (32 * it < H4) p1 += (i < H4) ? s4 : 0.f;
+      if (32 * it + 31 < 2 * H4) p2 += s4;
+      else if (32 * it < 2 * H4) p2 += (i < 2 * H4) ? s4 : 0.f;
+    }
+  }
+#ifdef MMS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MMS_STAMP(2);
+  if (FWD) {
+    if (ST4 > D4C && j < ST4 - D4C) img[D4C + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    p1 = half_wave_sum(p1);
+    p2 = half_wave_sum(p2);
+    wave_lds_sync();
+    MMS_STAMP(3);
+    const float dist = chain_sum_speculative_c<D4C>(img, p1, p2, j, grp * 32);
+    MMS_STAMP(4);
+    T = 1.0f / (1.0f + sqrtf(dist));            // :106-107
+    if (j == 0 && have) top_out[row] = T;
+  }
+  if (!BWD) return;
+
+  float4* dq4 = reinterpret_cast<float4*>(dq) + (size_t)row * D4C;
+  float4* da4 = reinterpret_cast<float4*>(da) + (size_t)row * D4C;
+  float4 t[NIT];
+  if (EXACT) {
+    const EuclidCoef k = euclid_coef(T, g);
+    bool any_risky = false;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      bool risky;
+      t[it] = euclid_tt4_fast(k, df[it], risky);
+      any_risky |= risky && ((it < NIT - 1) || last_ok);
+    }
+    if (any_risky) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) t[it] = euclid_tt4_exact(k, df[it]);
+    }
+  } else {
+    const float c = g * T * T * T;
+    const float r = (float)rcp_newton((double)(T - 1.0f) + 1e-9);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      t[it].x = (c * df[it].x) * r; t[it].y = (c * df[it].y) * r;
+      t[it].z = (c * df[it].z) * r; t[it].w = (c * df[it].w) * r;
+    }
+  }
+  MMS_STAMP(5);
+  if (have) {
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if (!((it < NIT - 1) || last_ok)) break;
+    // dq = 0 + tt ; da = 0 + (-tt)   (:176-177 zero, :219-220 accumulate once)
+    float4 o0, o1;
+    o0.x = 0.f + t[it].x; o0.y = 0.f + t[it].y; o0.z = 0.f + t[it].z; o0.w = 0.f + t[it].w;
+    o1.x = 0.f + (-t[it].x); o1.y = 0.f + (-t[it].y); o1.z = 0.f + (-t[it].z); o1.w = 0.f + (-t[it].w);
+    dq4[j + 32 * it] = o0;
+    da4[j + 32 * it] = o1;
+  }
   }
   MMS_STAMP(6);
 #ifdef MMS_STAMPS
@@ -789,10 +928,49 @@ static bool wave_ok(int D, const void* p0, const void* p1, const void* p2, const
   return vec4_ok(D, p0, p1, p2, p3) && D <= 1024;
 }
 
+// Backward arithmetic of the Euclidean term (include/mms.h: mms_set_euclid_backward_mode).
+static std::atomic<int> g_euclid_bwd_mode{-1};
+int euclid_backward_mode() {
+  int m = g_euclid_bwd_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = std::getenv("MMS_EUCLID_BWD");
+    m = (e && (!std::strcmp(e, "reference") || !std::strcmp(e, "exact") || !std::strcmp(e, "1")))
+            ? MMS_EUCLID_BWD_REFERENCE : MMS_EUCLID_BWD_FP32;
+    g_euclid_bwd_mode.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
+void set_euclid_backward_mode(int m) { g_euclid_bwd_mode.store(m, std::memory_order_relaxed); }
+
+// widths with a specialised kernel: 100-d, 200-d and 300-d GloVe (D4 = 25, 50, 75)
+static bool pair32_width(int D) { return D == 300 || D == 200 || D == 100; }
+
+template <bool FWD, bool BWD>
+static void launch_pair32(const float* q, const float* a, const float* top_in, const float* top_diff,
+                          float* top_out, float* dq, float* da, int N, int D, hipStream_t s) {
+  const unsigned grid = (unsigned)((N + 7) / 8);
+  const bool exact = BWD && euclid_backward_mode() == MMS_EUCLID_BWD_REFERENCE;
+#define MMS_P32(d4)                                                                                \
+  case 4 * d4:                                                                                     \
+    if (exact)                                                                                     \
+      hipLaunchKernelGGL((euclid_pair32_kernel<d4, FWD, BWD, true>), dim3(grid), dim3(256), 0, s,  \
+                         N, q, a, top_in, top_diff, top_out, dq, da);                              \
+    else                                                                                           \
+      hipLaunchKernelGGL((euclid_pair32_kernel<d4, FWD, BWD, false>), dim3(grid), dim3(256), 0, s, \
+                         N, q, a, top_in, top_diff, top_out, dq, da);                              \
+    break;
+  switch (D) { MMS_P32(25) MMS_P32(50) MMS_P32(75) }
+#undef MMS_P32
+}
+
 template <bool FWD, bool BWD>
 static void launch_rows_wave(const float* q, const float* a, const float* top_in,
                              const float* top_diff, float* top_out, float* dq, float* da, int N,
                              int D, hipStream_t s) {
+  if (pair32_width(D)) {
+    launch_pair32<FWD, BWD>(q, a, top_in, top_diff, top_out, dq, da, N, D, s);
+    return;
+  }
   const int D4 = D / 4;
   const int rw = wave_rw(D);
   const unsigned grid = (unsigned)((N + 4 * rw - 1) / (4 * rw));

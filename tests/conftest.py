@@ -35,3 +35,22 @@ def hiplib():
     from mms_answer_selection_amd import build, capi
     build.build_all()
     return capi.lib()
+
+
+@pytest.fixture(autouse=True)
+def _reference_backward_rounding(request):
+    """GPU tests assert the reference's BITS for the Euclidean backward term unless they say
+    otherwise: select MMS_EUCLID_BWD_REFERENCE around each of them (include/mms.h).  The product
+    default (fp32 arithmetic, <= 2 ulp) is exercised by tests/test_gpu_bwd_modes.py, smoke() and
+    bench.py."""
+    if "gpu" not in request.keywords:
+        yield
+        return
+    import torch
+    if not torch.cuda.is_available():
+        yield
+        return
+    from mms_answer_selection_amd import capi
+    capi.set_euclid_backward_mode("reference")
+    yield
+    capi.set_euclid_backward_mode("fp32")

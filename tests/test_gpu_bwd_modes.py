@@ -1,0 +1,91 @@
+"""The two arithmetic modes of the Euclidean backward term (include/mms.h:
+mms_set_euclid_backward_mode).  Forward scores are bit-identical to the oracle in both; the
+default fp32 mode keeps every gradient element within 2 ulp of the reference's value (the
+north-star bar is 1e-5 relative), the reference mode reproduces the bits."""
+import numpy as np
+import pytest
+import torch
+
+from mms_answer_selection_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(r, N, D, scale=0.4):
+    q = (r.standard_normal((N, 1, D)) * scale).astype(np.float32)
+    a = (r.standard_normal((N, 1, D)) * scale).astype(np.float32)
+    dT = r.standard_normal((N, 1, 1, 1)).astype(np.float32)
+    return q, a, dT
+
+
+def _ulps(x, ref):
+    return np.abs(x.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+
+
+@pytest.mark.parametrize("N,D", [(4096, 300), (4097, 300), (1, 300), (7, 200), (333, 200), (1000, 100), (2, 100)])
+def test_fp32_mode_is_within_two_ulp_and_forward_is_exact(N, D, oracle, hiplib):
+    r = np.random.default_rng(N * 1000 + D)
+    q, a, dT = _case(r, N, D)
+    top_ref, _, _ = oracle.simcross_forward(1, q, a)
+    dq_ref, da_ref, _, _ = oracle.simcross_backward(1, q, a, top_ref, dT)
+    qd, ad, dTd = (torch.from_numpy(x).cuda() for x in (q, a, dT))
+    capi.set_euclid_backward_mode("fp32")
+    assert capi.get_euclid_backward_mode() == "fp32"
+    top = torch.empty(N, 1, 1, 1, device="cuda")
+    dq = torch.full_like(qd, 7.0)
+    da = torch.full_like(ad, 7.0)
+    capi.simcross_forward_backward(1, qd, ad, dTd, top, dq, da)
+    t, g, h = top.cpu().numpy(), dq.cpu().numpy(), da.cpu().numpy()
+    assert (t.view(np.uint32) == top_ref.view(np.uint32)).all()          # ranking-relevant output: exact
+    assert _ulps(g, dq_ref).max() <= 2 and _ulps(h, da_ref).max() <= 2
+    np.testing.assert_allclose(g, dq_ref, rtol=1e-5, atol=0)             # the stated bar, with room
+    assert (h == -g).all()
+    # the unfused entry points (Layer API: Forward then Backward) follow the same mode
+    top2 = torch.empty_like(top)
+    capi.simcross_forward(1, qd, ad, top2)
+    dq2 = torch.empty_like(qd)
+    da2 = torch.empty_like(ad)
+    capi.simcross_backward(1, qd, ad, top2, dTd, dq2, da2)
+    assert torch.equal(top2, top) and torch.equal(dq2, dq) and torch.equal(da2, da)
+    # reference mode: the bits
+    capi.set_euclid_backward_mode("reference")
+    assert capi.get_euclid_backward_mode() == "reference"
+    capi.simcross_forward_backward(1, qd, ad, dTd, top, dq, da)
+    assert (dq.cpu().numpy().view(np.uint32) == dq_ref.view(np.uint32)).all()
+    assert (da.cpu().numpy().view(np.uint32) == da_ref.view(np.uint32)).all()
+
+
+def test_fp32_mode_near_identical_pairs_and_extreme_scales(oracle, hiplib):
+    """T -> 1 (den -> 1e-9) and tiny / huge coordinates: still within 2 ulp of the reference
+    expression wherever the reference value is a normal number."""
+    r = np.random.default_rng(77)
+    N, D = 64, 300
+    q, a, dT = _case(r, N, D)
+    a[:16] = q[:16]                                    # distance 0: T == 1, den == 1e-9
+    a[16:32] = q[16:32] + np.float32(1e-6) * r.standard_normal((16, 1, D)).astype(np.float32)
+    q[32:40] *= np.float32(1e-12)
+    a[32:40] *= np.float32(1e-12)
+    q[40:48] *= np.float32(1e6)
+    a[40:48] *= np.float32(1e6)
+    top_ref, _, _ = oracle.simcross_forward(1, q, a)
+    dq_ref, _, _, _ = oracle.simcross_backward(1, q, a, top_ref, dT)
+    qd, ad, dTd = (torch.from_numpy(x).cuda() for x in (q, a, dT))
+    capi.set_euclid_backward_mode("fp32")
+    top = torch.empty(N, 1, 1, 1, device="cuda")
+    dq = torch.empty_like(qd)
+    da = torch.empty_like(ad)
+    capi.simcross_forward_backward(1, qd, ad, dTd, top, dq, da)
+    g = dq.cpu().numpy()
+    assert (top.cpu().numpy().view(np.uint32) == top_ref.view(np.uint32)).all()
+    normal = np.abs(dq_ref) >= np.float32(1.2e-38)
+    assert _ulps(g, dq_ref)[normal].max() <= 2
+    if (~normal).any():                                # subnormal / zero reference values: a few quanta at most
+        assert np.abs(g[~normal].astype(np.float64) - dq_ref[~normal]).max() <= 1e-44
+
+
+def test_mode_setter_validates(hiplib):
+    assert hiplib.mms_set_euclid_backward_mode(7) == 1            # MMS_ERR_INVALID_ARG
+    capi.set_euclid_backward_mode("reference")
+    assert hiplib.mms_get_euclid_backward_mode() == 1
+    capi.set_euclid_backward_mode("fp32")
+    assert hiplib.mms_get_euclid_backward_mode() == 0
