@@ -11,6 +11,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "mms_common.h"
+
 namespace mms {
 
 // Per-(pair,j,k) coefficients.  c = ((g*T)*T)*T ; den = (double)(T-1) + 1e-9 ;
@@ -273,57 +275,71 @@ __device__ __forceinline__ float chain_sum_speculative(const float4* img4, int D
 }
 
 // Compile-time-length variants for the widths the wave-pair kernel is specialised
-// for (simcross_elementwise.hip: euclid_pair32_kernel).  N4 is a constant, so the
-// segment's N4 LDS reads are all issued up front into registers (two waves per
-// SIMD leave 256 VGPRs per lane) and the chain is N4*4 straight-line packed adds:
-// no loop control, no register rotation.
-template <int N4>
-__device__ __forceinline__ float2v chain_sum_lds_pk_c(const float4* r4, float2v init) {
-  float4 v[N4];
+// for (simcross_elementwise.hip: euclid_pair32_kernel).  H4 (float4s per segment)
+// is a constant, so
+//  * the segment's LDS reads are all issued up front into registers (two waves
+//    per SIMD leave 256 VGPRs per lane) -- and BEFORE the window centres are
+//    reduced, so that LDS latency hides behind the DPP sums;
+//  * the chain is H4*4 straight-line packed adds: no loop control, no register
+//    rotation, and op_sel broadcasts each addend lane-locally;
+//  * the two look-ups that stitch the segments together run on the SCALAR unit
+//    (v_readlane with a computed lane, s_sub/s_cmp) instead of three dependent
+//    ds_bpermute round trips;
+//  * a miss anywhere (never observed on real data; forced by the adversarial
+//    tests) sends the whole wave to ONE exact re-walk of the full image.
+template <int H4>
+struct SpecSegment {
+  float4 v[H4];
+  __device__ __forceinline__ void load(const float4* r4) {
 #pragma unroll
-  for (int u = 0; u < N4; ++u) v[u] = r4[u];
-  float2v s = init;
-#pragma unroll
-  for (int u = 0; u < N4; ++u) {
-    // two 64-bit halves, each broadcast lane-locally with op_sel (no v_mov for .y / .w)
-    const float2v lo = {v[u].x, v[u].y}, hi = {v[u].z, v[u].w};
-    s = s + __builtin_shufflevector(lo, lo, 0, 0);
-    s = s + __builtin_shufflevector(lo, lo, 1, 1);
-    s = s + __builtin_shufflevector(hi, hi, 0, 0);
-    s = s + __builtin_shufflevector(hi, hi, 1, 1);
+    for (int u = 0; u < H4; ++u) v[u] = r4[u];
   }
-  return s;
-}
+  __device__ __forceinline__ float2v chain(float2v s) const {
+#pragma unroll
+    for (int u = 0; u < H4; ++u) {
+      const float2v lo = {v[u].x, v[u].y}, hi = {v[u].z, v[u].w};
+      s = s + __builtin_shufflevector(lo, lo, 0, 0);
+      s = s + __builtin_shufflevector(lo, lo, 1, 1);
+      s = s + __builtin_shufflevector(hi, hi, 0, 0);
+      s = s + __builtin_shufflevector(hi, hi, 1, 1);
+    }
+    return s;
+  }
+};
 
-// chain_sum_speculative<32> with D4 known at compile time; `lead` is 0 or 32.
-template <int D4C>
-__device__ __forceinline__ float chain_sum_speculative_c(const float4* img4, float pred1, float pred2,
-                                                         int j, int lead) {
+// segment of lane j of a 32-lane group: j = 0 walks segment 0 from 0.0f exactly
+__device__ __forceinline__ int spec_seg32(int j) { return (j == 0) ? 0 : (j <= SpecPlan<32>::L1 ? 1 : 2); }
+
+__device__ __forceinline__ float2v spec_start32(float pred1, float pred2, int j) {
   typedef SpecPlan<32> P;
-  constexpr int h4 = (D4C + 2) / 3;
-  const int seg = (j == 0) ? 0 : (j <= P::L1 ? 1 : 2);
-  const int c0 = (seg == 1) ? 2 * (j - 1) - P::H1 : 2 * (j - 1 - P::L1) - P::H2;
+  const int seg = spec_seg32(j);
+  const int c0 = (seg == 1) ? 2 * (j - 1) - P::H1 : 2 * (j - 1 - P::L1) - P::H2;   // ulp offset of slot 0
   const int pbits = __float_as_int(seg == 1 ? pred1 : pred2);
   float2v start;
   start.x = (seg == 0) ? 0.0f : __int_as_float(pbits + c0);
   start.y = (seg == 0) ? 0.0f : __int_as_float(pbits + c0 + 1);
-  __builtin_amdgcn_s_setprio(3);
-  const float2v end = chain_sum_lds_pk_c<h4>(img4 + seg * h4, start);
-  const float s1 = __shfl(end.x, lead, 64);
-  const int k1 = __float_as_int(s1) - __float_as_int(pred1) + P::H1;
-  const bool hit1 = (k1 >= 0) && (k1 <= 2 * P::H1);
-  const int l1 = lead + 1 + ((hit1 ? k1 : 0) >> 1);
-  const float e1x = __shfl(end.x, l1, 64), e1y = __shfl(end.y, l1, 64);
-  float s2 = (k1 & 1) ? e1y : e1x;
-  if (!hit1) { MMS_COUNT_MISS(); s2 = chain_sum_lds(img4 + h4, h4, s1); }
-  const int k2 = __float_as_int(s2) - __float_as_int(pred2) + P::H2;
-  const bool hit2 = (k2 >= 0) && (k2 <= 2 * P::H2);
-  const int l2 = lead + 1 + P::L1 + ((hit2 ? k2 : 0) >> 1);
-  const float e2x = __shfl(end.x, l2, 64), e2y = __shfl(end.y, l2, 64);
-  float s3 = (k2 & 1) ? e2y : e2x;
-  if (!hit2) { MMS_COUNT_MISS(); s3 = chain_sum_lds(img4 + 2 * h4, h4, s2); }
-  __builtin_amdgcn_s_setprio(0);
-  return s3;
+  return start;
+}
+
+// Stitch the three segments of BOTH pairs of a wave at once (lanes 0-31 / 32-63), on the
+// VALU: the lane whose start value equals the running total contributes its end value, and
+// an OR-reduction over the half (DPP, no LDS) hands it to every lane.  Sums of squares are
+// never negative, so bit 31 is free to carry "some lane matched".  Three reductions of six
+// dependent DPP steps replace three ds_bpermute round trips (or ~40 dependent scalar ops).
+// Returns the pair's total in every lane of its half; `hit` is false on a window miss.
+__device__ __forceinline__ float spec_resolve_halves(float2v start, float2v end, int j, bool* hit) {
+  constexpr unsigned F = 0x80000000u;
+  const int seg = spec_seg32(j);
+  const unsigned sx = __float_as_uint(start.x), sy = __float_as_uint(start.y);
+  const unsigned ex = __float_as_uint(end.x) | F, ey = __float_as_uint(end.y) | F;
+  const unsigned s1 = half_wave_or(j == 0 ? ex : 0u) & ~F;                 // segment 0 ends here
+  const unsigned m1 = (seg == 1) ? (sx == s1 ? ex : (sy == s1 ? ey : 0u)) : 0u;
+  const unsigned s2f = half_wave_or(m1);
+  const unsigned s2 = s2f & ~F;
+  const unsigned m2 = (seg == 2) ? (sx == s2 ? ex : (sy == s2 ? ey : 0u)) : 0u;
+  const unsigned s3f = half_wave_or(m2);
+  *hit = ((s2f & s3f) & F) != 0;
+  return __uint_as_float(s3f & ~F);
 }
 
 // Compiler-level ordering between LDS writes of some lanes and LDS reads of

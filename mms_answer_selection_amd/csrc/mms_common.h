@@ -53,6 +53,20 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
+// Bitwise OR across each 32-lane half of a wave, same data movement as half_wave_sum.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_or(unsigned v) {
+  return v | (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned half_wave_or(unsigned v) {
+  v = dpp_or<0xB1>(v);
+  v = dpp_or<0x4E>(v);
+  v = dpp_or<0x141>(v);
+  v = dpp_or<0x140>(v);
+  const auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  return sw[0] | sw[1];
+}
+
 // Sum across a workgroup of THREADS (multiple of 64) threads; result valid in
 // every thread.  `red` is LDS scratch of THREADS/64 floats.  Fixed order.
 template <int THREADS>

@@ -38,7 +38,7 @@ __device__ unsigned long long* mms_stamp_buf = nullptr;
 #define MMS_STAMP(k)                                                                        \
   do {                                                                                      \
     if (mms_stamp_buf && (threadIdx.x & 63) == 0)                                           \
-      mms_stamp_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+      mms_stamp_buf[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define MMS_STAMP(k) do {} while (0)
@@ -226,8 +226,8 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
 //   false: fp32 throughout, tt = (c*(q-a)) * fl32(1/den): at most 2 ulp from the
 //          reference's value (1.2e-7 relative against the 1e-5 bar), a third of
 //          the instructions.  The FORWARD value T is bit-exact in both.
-template <int D4C, bool FWD, bool BWD, bool EXACT>
-__global__ __launch_bounds__(256) void euclid_pair32_kernel(
+template <int D4C, bool FWD, bool BWD, bool EXACT, int WPB>
+__global__ __launch_bounds__(64 * WPB) void euclid_pair32_kernel(
     int N, const float* __restrict__ q, const float* __restrict__ a,
     const float* __restrict__ top_in, const float* __restrict__ top_diff,
     float* __restrict__ top_out, float* __restrict__ dq, float* __restrict__ da) {
@@ -236,12 +236,12 @@ __global__ __launch_bounds__(256) void euclid_pair32_kernel(
   constexpr int NIT = (D4C + 31) / 32;
   constexpr int LASTN = D4C - 32 * (NIT - 1);    // lanes with a float4 in the last slot
   constexpr int H4 = (D4C + 2) / 3, ST4 = 3 * H4;
-  __shared__ float4 lds4[FWD ? 4 * 2 * ST4 : 1];
+  __shared__ float4 lds4[FWD ? WPB * 2 * ST4 : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int grp = lane >> 5, j = lane & 31;
   // No early exit: a wave past the end works on the last pair and stores nothing, so that no
   // branch (and no wait on the kernel arguments) stands between wave start and the loads.
-  const int want = (blockIdx.x * 4 + wave) * 2 + grp;
+  const int want = (blockIdx.x * WPB + wave) * 2 + grp;
   const bool have = want < N;
   const int row = have ? want : N - 1;
   const float4* q4 = reinterpret_cast<const float4*>(q) + (size_t)row * D4C;
@@ -289,13 +289,35 @@ __global__ __launch_bounds__(256) void euclid_pair32_kernel(
   MMS_STAMP(2);
   if (FWD) {
     if (ST4 > D4C && j < ST4 - D4C) img[D4C + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    wave_lds_sync();
+    SpecSegment<H4> sg;
+    sg.load(img + spec_seg32(j) * H4);          // in flight while the window centres are reduced
     p1 = half_wave_sum(p1);
     p2 = half_wave_sum(p2);
-    wave_lds_sync();
     MMS_STAMP(3);
-    const float dist = chain_sum_speculative_c<D4C>(img, p1, p2, j, grp * 32);
+    __builtin_amdgcn_s_setprio(3);
+    const float2v start = spec_start32(p1, p2, j);
+#if defined(MMS_ABLATE) && MMS_ABLATE >= 12     // dev-only timing ablations (tools/ablate.sh)
+    float dist = p2 + sg.v[0].x;
+#elif defined(MMS_ABLATE) && MMS_ABLATE == 11
+    const float2v end = sg.chain(start);
+    float dist = end.x + end.y;
+#else
+    const float2v end = sg.chain(start);
+    bool hit;
+    float dist = spec_resolve_halves(start, end, j, &hit);
+    if (!hit) {                                 // uniform per half; exact re-walk of this lane's pair
+      MMS_COUNT_MISS();
+      dist = chain_sum_lds(img, ST4, 0.0f);
+    }
+#endif
+    __builtin_amdgcn_s_setprio(0);
     MMS_STAMP(4);
+#if defined(MMS_ABLATE) && MMS_ABLATE >= 13
+    T = dist;
+#else
     T = 1.0f / (1.0f + sqrtf(dist));            // :106-107
+#endif
     if (j == 0 && have) top_out[row] = T;
   }
   if (!BWD) return;
@@ -945,22 +967,30 @@ void set_euclid_backward_mode(int m) { g_euclid_bwd_mode.store(m, std::memory_or
 // widths with a specialised kernel: 100-d, 200-d and 300-d GloVe (D4 = 25, 50, 75)
 static bool pair32_width(int D) { return D == 300 || D == 200 || D == 100; }
 
-template <bool FWD, bool BWD>
-static void launch_pair32(const float* q, const float* a, const float* top_in, const float* top_diff,
-                          float* top_out, float* dq, float* da, int N, int D, hipStream_t s) {
-  const unsigned grid = (unsigned)((N + 7) / 8);
+template <bool FWD, bool BWD, int WPB>
+static void launch_pair32w(const float* q, const float* a, const float* top_in, const float* top_diff,
+                           float* top_out, float* dq, float* da, int N, int D, hipStream_t s) {
+  const unsigned grid = (unsigned)((N + 2 * WPB - 1) / (2 * WPB));
   const bool exact = BWD && euclid_backward_mode() == MMS_EUCLID_BWD_REFERENCE;
-#define MMS_P32(d4)                                                                                \
-  case 4 * d4:                                                                                     \
-    if (exact)                                                                                     \
-      hipLaunchKernelGGL((euclid_pair32_kernel<d4, FWD, BWD, true>), dim3(grid), dim3(256), 0, s,  \
-                         N, q, a, top_in, top_diff, top_out, dq, da);                              \
-    else                                                                                           \
-      hipLaunchKernelGGL((euclid_pair32_kernel<d4, FWD, BWD, false>), dim3(grid), dim3(256), 0, s, \
-                         N, q, a, top_in, top_diff, top_out, dq, da);                              \
+#define MMS_P32(d4)                                                                                  \
+  case 4 * d4:                                                                                       \
+    if (exact)                                                                                       \
+      hipLaunchKernelGGL((euclid_pair32_kernel<d4, FWD, BWD, true, WPB>), dim3(grid), dim3(64 * WPB), \
+                         0, s, N, q, a, top_in, top_diff, top_out, dq, da);                          \
+    else                                                                                             \
+      hipLaunchKernelGGL((euclid_pair32_kernel<d4, FWD, BWD, false, WPB>), dim3(grid),               \
+                         dim3(64 * WPB), 0, s, N, q, a, top_in, top_diff, top_out, dq, da);          \
     break;
   switch (D) { MMS_P32(25) MMS_P32(50) MMS_P32(75) }
 #undef MMS_P32
+}
+
+// Eight waves (16 pairs) per workgroup: N = 4096 is then 256 workgroups, one per CU, two waves
+// per SIMD -- measured 3 % faster HBM-cold than 512 workgroups of four waves (dispatch ramp).
+template <bool FWD, bool BWD>
+static void launch_pair32(const float* q, const float* a, const float* top_in, const float* top_diff,
+                          float* top_out, float* dq, float* da, int N, int D, hipStream_t s) {
+  launch_pair32w<FWD, BWD, 8>(q, a, top_in, top_diff, top_out, dq, da, N, D, s);
 }
 
 template <bool FWD, bool BWD>

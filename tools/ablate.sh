@@ -4,7 +4,7 @@
 set -e
 ROOT=$(pwd)
 SRCS=$(ls mms_answer_selection_amd/csrc/*.hip)
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -I include -I mms_answer_selection_amd/csrc"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=16 -I include -I mms_answer_selection_amd/csrc"
 for v in "$@"; do
   mkdir -p /tmp/abl$v
   hipcc $FLAGS -DMMS_ABLATE=$v $SRCS -o /tmp/abl$v/libmms_hip.so
