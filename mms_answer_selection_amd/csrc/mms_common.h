@@ -19,6 +19,18 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
+// Write-once streaming stores (bottom diffs: written here, read by another kernel much
+// later): the non-temporal form does not allocate in L2, so the NEXT launch's reads are not
+// queued behind this launch's write-backs.  Measured on cfg 2, HBM-cold: 6.1 -> 5.35 us/step.
+typedef float mms_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_store(float4* p, const float4& v) {
+  __builtin_nontemporal_store((mms_v4f){v.x, v.y, v.z, v.w}, reinterpret_cast<mms_v4f*>(p));
+}
+template <typename V>
+__device__ __forceinline__ void stream_store_vec(V* p, const V& v) {   // V: an ext_vector_type
+  __builtin_nontemporal_store(v, p);
+}
+
 // Sum across the 64 lanes of a wave in a fixed order (deterministic); every
 // lane ends with the total.  DPP cross-lane adds, no LDS round trips: xor-1 and
 // xor-2 inside quads, half-mirror and mirror inside each row of 16, then

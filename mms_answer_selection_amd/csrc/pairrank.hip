@@ -232,9 +232,9 @@ __global__ __launch_bounds__(256) void triplet_wave_kernel(
     oq.z = (0.f + tp.z) + (0.f + tn.z); oq.w = (0.f + tp.w) + (0.f + tn.w);
     op.x = 0.f + (-tp.x); op.y = 0.f + (-tp.y); op.z = 0.f + (-tp.z); op.w = 0.f + (-tp.w);
     on.x = 0.f + (-tn.x); on.y = 0.f + (-tn.y); on.z = 0.f + (-tn.z); on.w = 0.f + (-tn.w);
-    dq4[i] = oq;
-    dp4[i] = op;
-    dn4[i] = on;
+    stream_store(dq4 + i, oq);
+    stream_store(dp4 + i, op);
+    stream_store(dn4 + i, on);
   }
 }
 

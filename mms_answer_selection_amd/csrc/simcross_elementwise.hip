@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
     float4 o0, o1;
     o0.x = 0.f + t[it].x; o0.y = 0.f + t[it].y; o0.z = 0.f + t[it].z; o0.w = 0.f + t[it].w;
     o1.x = 0.f + (-t[it].x); o1.y = 0.f + (-t[it].y); o1.z = 0.f + (-t[it].z); o1.w = 0.f + (-t[it].w);
-    dq4[i] = o0;
-    da4[i] = o1;
+    stream_store(dq4 + i, o0);
+    stream_store(da4 + i, o1);
   }
   MMS_STAMP(6);
 #ifdef MMS_STAMPS
@@ -356,8 +356,8 @@ __global__ __launch_bounds__(64 * WPB) void euclid_pair32_kernel(
     float4 o0, o1;
     o0.x = 0.f + t[it].x; o0.y = 0.f + t[it].y; o0.z = 0.f + t[it].z; o0.w = 0.f + t[it].w;
     o1.x = 0.f + (-t[it].x); o1.y = 0.f + (-t[it].y); o1.z = 0.f + (-t[it].z); o1.w = 0.f + (-t[it].w);
-    dq4[j + 32 * it] = o0;
-    da4[j + 32 * it] = o1;
+    stream_store(dq4 + j + 32 * it, o0);
+    stream_store(da4 + j + 32 * it, o1);
   }
   }
   MMS_STAMP(6);
@@ -455,8 +455,8 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_f16_kernel(
       o1[4 * hh + 0] = (_Float16)(0.f + (-t.x)); o1[4 * hh + 1] = (_Float16)(0.f + (-t.y));
       o1[4 * hh + 2] = (_Float16)(0.f + (-t.z)); o1[4 * hh + 3] = (_Float16)(0.f + (-t.w));
     }
-    dq8[i] = o0;
-    da8[i] = o1;
+    stream_store_vec(dq8 + i, o0);
+    stream_store_vec(da8 + i, o1);
   }
 }
 
@@ -609,8 +609,8 @@ __global__ __launch_bounds__(256) void cosine_rows_kernel(
       o1.y = 0.f + g * (x.y / n0 / n1 - y.y * T / n11);
       o1.z = 0.f + g * (x.z / n0 / n1 - y.z * T / n11);
       o1.w = 0.f + g * (x.w / n0 / n1 - y.w * T / n11);
-      dq4[i] = o0;
-      da4[i] = o1;
+      stream_store(dq4 + i, o0);
+      stream_store(da4 + i, o1);
     }
   } else {
     for (int i = lane; i < D; i += 64) {

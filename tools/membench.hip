@@ -33,6 +33,25 @@ __global__ __launch_bounds__(256) void copy2_wave_kernel(const float4* __restric
 #pragma unroll
   for (int it = 0; it < 3; ++it) { int i = lane + 64 * it; if (i < 150) { dq[b + i] = x[it]; da[b + i] = y[it]; } }
 }
+// the same copy with non-temporal (streaming) stores, 8 waves per workgroup like the library kernel
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void copy2_wave_nt_kernel(const float4* __restrict__ q, const float4* __restrict__ a,
+                                                            float4* __restrict__ dq, float4* __restrict__ da, int n) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = min((blockIdx.x * 8 + wave) * 2 + (lane >> 5), n - 1), j = lane & 31;
+  const size_t b = (size_t)row * D4;
+  float4 x[3], y[3];
+#pragma unroll
+  for (int it = 0; it < 3; ++it) { int i = j + 32 * it; int ii = i < D4 ? i : 0; x[it] = q[b + ii]; y[it] = a[b + ii]; }
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    int i = j + 32 * it;
+    if (i < D4) {
+      __builtin_nontemporal_store((v4f_nt){x[it].x, x[it].y, x[it].z, x[it].w}, (v4f_nt*)(dq + b + i));
+      __builtin_nontemporal_store((v4f_nt){y[it].x, y[it].y, y[it].z, y[it].w}, (v4f_nt*)(da + b + i));
+    }
+  }
+}
 __global__ __launch_bounds__(256) void read2_kernel(const float4* __restrict__ q, const float4* __restrict__ a,
                                                     float* __restrict__ out, int n4) {
   int i = blockIdx.x * 256 + threadIdx.x;
@@ -92,6 +111,8 @@ int main(int argc, char** argv) {
 
   run("copy2 (1 float4/thread)", [&](Slot& x, hipStream_t t) {
     hipLaunchKernelGGL(copy2_kernel, dim3((n4 + 255) / 256), dim3(256), 0, t, (const float4*)x.q, (const float4*)x.a, (float4*)x.dq, (float4*)x.da, n4); }, 4.0 * nb);
+  run("copy2 pair-structured, nt stores", [&](Slot& x, hipStream_t t) {
+    hipLaunchKernelGGL(copy2_wave_nt_kernel, dim3((N + 15) / 16), dim3(512), 0, t, (const float4*)x.q, (const float4*)x.a, (float4*)x.dq, (float4*)x.da, N); }, 4.0 * nb);
   run("copy2 wave-structured", [&](Slot& x, hipStream_t t) {
     hipLaunchKernelGGL(copy2_wave_kernel, dim3((N + 7) / 8), dim3(256), 0, t, (const float4*)x.q, (const float4*)x.a, (float4*)x.dq, (float4*)x.da, N); }, 4.0 * nb);
   run("read2", [&](Slot& x, hipStream_t t) {
