@@ -269,8 +269,8 @@ def run(args):
         step_us_ev = ev_ms * 1e3 / args.steps            # HIP events on the launch stream
         achieved = B_UNFUSED / (step_us_ev * 1e-6) / 1e9 if args.path != "triplet" else None
         value = world * N_PAIRS * args.steps / wall
-        kernel = {"fused": "mms::euclid_rows_wave_kernel<3,true,true> (SimCross Euclid fwd+bwd, one launch)",
-                  "layers": "mms::euclid_rows_wave_kernel<3,true,false> + <3,false,true>",
+        kernel = {"fused": "mms::euclid_pair32_kernel<75,true,true,...> (SimCross Euclid fwd+bwd, one launch)",
+                  "layers": "mms::euclid_pair32_kernel<75,true,false,...> + <75,false,true,...>",
                   "triplet": "mms::triplet_wave_kernel<3> + loss_finish_kernel"}[args.path]
         out = {
             "metric": "QA pairs/sec (fwd+bwd) at batch 4096, 300-d; % HBM roofline",
@@ -281,6 +281,9 @@ def run(args):
             "config": {"workload": "cfg2: SimCross dist_mode=1 (Euclid) fwd+bwd, q,a (4096,1,300) fp32 per GPU",
                        "pairs_per_gpu": N_PAIRS, "dim": DIM, "global_batch": world * N_PAIRS,
                        "path": args.path, "launches_per_step": launches_per_step,
+                       "euclid_backward_arithmetic": capi.get_euclid_backward_mode() +
+                       (" (scores bit-identical to the CPU code; gradient elements <= 2 ulp from it, bar 1e-5)"
+                        if capi.get_euclid_backward_mode() == "fp32" else " (gradients bit-identical too)"),
                        "residency": "cache-warm (1 batch)" if args.warm else
                                     "HBM-cold ring of %d batches (%.2f GiB)" % (ring, ring * 19.7e6 / 2**30),
                        "hip_graph_group": G if use_graph else 0,
@@ -315,15 +318,24 @@ def run(args):
         dist.destroy_process_group()
 
 
+DEFAULT_BWD_MODE = os.environ.get("MMS_EUCLID_BWD", "fp32")
+if DEFAULT_BWD_MODE not in ("fp32", "reference"):
+    DEFAULT_BWD_MODE = "reference" if DEFAULT_BWD_MODE in ("exact", "1") else "fp32"
+
+
 def variants(torch, capi, args):
     """Short interleaved measurements of the other entry points / residency, same device."""
     res = {}
     K, G = 1024, 16
     for name, path, ring in (("fused_cold", "fused", 64), ("fused_warm", "fused", 1),
+                             ("fused_cold_reference_rounding_bwd", "fused", 64),
                              ("layers_cold", "layers", 64), ("layers_warm", "layers", 1),
                              ("triplet_cold", "triplet", 48)):
-        if path == args.path and ((ring == 1) == args.warm):
+        ref_mode = name.endswith("reference_rounding_bwd")
+        if path == args.path and ((ring == 1) == args.warm) and not ref_mode:
             continue
+        # the launcher picks the kernel variant at capture time (include/mms.h)
+        capi.set_euclid_backward_mode("reference" if ref_mode else DEFAULT_BWD_MODE)
         bt = Batches(torch, ring, path, 0)
         step = make_step(capi, bt, path)
         top = torch.empty(G, N_PAIRS, 1, 1, 1, device="cuda")
@@ -359,6 +371,7 @@ def variants(torch, capi, args):
             res[name]["frac_hbm_unfused_bytes"] = B_UNFUSED / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
         del bt, graphs
         torch.cuda.empty_cache()
+    capi.set_euclid_backward_mode(DEFAULT_BWD_MODE)
     res.update(other_configs(torch, capi))
     return res
 

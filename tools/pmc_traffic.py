@@ -70,7 +70,8 @@ def main():
                       "FETCH_SIZE_KiB_per_launch_raw": f_kib, "WRITE_SIZE_KiB_per_launch_raw": w_kib,
                       "hbm_bytes_per_launch": hbm,
                       "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of 16B/lane streaming reads)"}
-        if "euclid_rows_wave_kernel" in k and "true, true" in k.replace("(bool)1", "true"):
+        kn = k.replace("(bool)1", "true")
+        if ("euclid_pair32_kernel" in kn or "euclid_rows_wave_kernel" in kn) and "true, true" in kn:
             traffic["fused"] = {"kernel": k, "hbm_bytes_per_launch": hbm}
     json.dump(summary, open(os.path.join(out, rnd + "_pmc.json"), "w"), indent=1)
     if traffic:
