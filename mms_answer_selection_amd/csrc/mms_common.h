@@ -65,6 +65,13 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
+// Per-lane (a, b) -> lanes 0-31 get a[l] + a[l+32], lanes 32-63 get b[l-32] + b[l]: the first
+// step of reducing two quantities of a whole wave into one half each (v_permlane32_swap).
+__device__ __forceinline__ float swap_halves_add(float a, float b) {
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+
 // Bitwise OR across each 32-lane half of a wave, same data movement as half_wave_sum.
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_or(unsigned v) {

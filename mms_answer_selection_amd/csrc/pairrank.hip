@@ -15,6 +15,8 @@
 
 namespace mms {
 
+int euclid_backward_mode();   // simcross_elementwise.hip
+
 struct PairTerm {
   float ordered, similar, term;
 };
@@ -72,7 +74,18 @@ __global__ __launch_bounds__(kPairThreads) void loss_finish_kernel(
     const float* __restrict__ partials, int n, int count, float* __restrict__ loss) {
   __shared__ float red[kPairThreads / 64];
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += kPairThreads) s += partials[i];
+  // eight independent loads in flight per thread (a one-block kernel is pure latency: a
+  // load-add-load-add loop costs one memory round trip per element), added in index order
+  for (int base = threadIdx.x; base < n; base += 8 * kPairThreads) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * kPairThreads;
+      v[u] = partials[i < n ? i : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (base + u * kPairThreads < n) ? v[u] : 0.f;
+  }
   s = block_sum<kPairThreads>(s, red);
   if (threadIdx.x == 0) *loss = s / (float)count;
 }
@@ -238,6 +251,131 @@ __global__ __launch_bounds__(256) void triplet_wave_kernel(
   }
 }
 
+// Width-specialised variant (D = 100 / 200 / 300), the triplet counterpart of
+// euclid_pair32_kernel (simcross_elementwise.hip): D4C known at compile time, all 64 lanes
+// hold float4s lane, lane+64 of q, a+ and a-; the window centres of the positive branch are
+// reduced INTO lanes 0-31 and those of the negative branch into lanes 32-63 with one
+// v_permlane32_swap + a half-wave DPP sum each; the chain is straight-line packed adds fed
+// by LDS reads issued before the reductions; the stitch is the DPP OR-reduction; eight
+// waves per workgroup, no early exit, N first for the kernarg preload, streaming stores.
+// EXACT as in euclid_pair32_kernel (include/mms.h: mms_set_euclid_backward_mode).
+template <int D4C, bool EXACT, int WPB>
+__global__ __launch_bounds__(64 * WPB) void triplet32_kernel(
+    int N, float margin, float s0, float s1, const float* __restrict__ q,
+    const float* __restrict__ ap, const float* __restrict__ an, const float* __restrict__ y,
+    float* __restrict__ s_pos, float* __restrict__ s_neg, float* __restrict__ partials,
+    float* __restrict__ dq, float* __restrict__ dap, float* __restrict__ dan) {
+  constexpr int NIT = (D4C + 63) / 64;
+  constexpr int LASTN = D4C - 64 * (NIT - 1);
+  constexpr int H4 = (D4C + 2) / 3, ST4 = 3 * H4;
+  __shared__ float4 lds4[WPB * 2 * ST4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int want = blockIdx.x * WPB + wave;
+  const bool have = want < N;
+  const int row = have ? want : N - 1;           // a wave past the end recomputes the last triplet, stores nothing
+  const size_t base4 = (size_t)row * D4C;
+  const float4* q4 = reinterpret_cast<const float4*>(q) + base4;
+  const float4* p4 = reinterpret_cast<const float4*>(ap) + base4;
+  const float4* m4 = reinterpret_cast<const float4*>(an) + base4;
+  const bool last_ok = (LASTN >= 64) || (lane < LASTN);
+  float4* sqp = lds4 + (size_t)wave * 2 * ST4;
+  float4* sqn = sqp + ST4;
+
+  float4 x[NIT], u[NIT], v[NIT], dp[NIT], dn[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = (it < NIT - 1 || last_ok) ? lane + 64 * it : 0;
+    x[it] = q4[i]; u[it] = p4[i]; v[it] = m4[i];
+  }
+  const float yy = y[row];
+  float pp1 = 0.f, pp2 = 0.f, pn1 = 0.f, pn2 = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const bool valid = (it < NIT - 1) || last_ok;
+    const int i = lane + 64 * it;
+    dp[it].x = x[it].x - u[it].x; dp[it].y = x[it].y - u[it].y;
+    dp[it].z = x[it].z - u[it].z; dp[it].w = x[it].w - u[it].w;
+    dn[it].x = x[it].x - v[it].x; dn[it].y = x[it].y - v[it].y;
+    dn[it].z = x[it].z - v[it].z; dn[it].w = x[it].w - v[it].w;
+    float4 a, b;
+    a.x = dp[it].x * dp[it].x; a.y = dp[it].y * dp[it].y;
+    a.z = dp[it].z * dp[it].z; a.w = dp[it].w * dp[it].w;
+    b.x = dn[it].x * dn[it].x; b.y = dn[it].y * dn[it].y;
+    b.z = dn[it].z * dn[it].z; b.w = dn[it].w * dn[it].w;
+    if (valid) { sqp[i] = a; sqn[i] = b; }
+    const float a4 = valid ? (a.x + a.y) + (a.z + a.w) : 0.f;
+    const float b4 = valid ? (b.x + b.y) + (b.z + b.w) : 0.f;
+    if (64 * it + 63 < H4) { pp1 += a4; pn1 += b4; }
+    else if (64 * it < H4) { pp1 += (i < H4) ? a4 : 0.f; pn1 += (i < H4) ? b4 : 0.f; }
+    if (64 * it + 63 < 2 * H4) { pp2 += a4; pn2 += b4; }
+    else if (64 * it < 2 * H4) { pp2 += (i < 2 * H4) ? a4 : 0.f; pn2 += (i < 2 * H4) ? b4 : 0.f; }
+  }
+  if (ST4 > D4C && lane < 2 * (ST4 - D4C))
+    sqp[(lane / (ST4 - D4C)) * ST4 + D4C + (lane % (ST4 - D4C))] = make_float4(0.f, 0.f, 0.f, 0.f);
+  wave_lds_sync();
+  const int br = lane >> 5, j = lane & 31;       // branch handled by this half-wave
+  SpecSegment<H4> sg;
+  sg.load((br ? sqn : sqp) + spec_seg32(j) * H4);
+  // positive totals into lanes 0-31, negative totals into lanes 32-63
+  const float p1 = half_wave_sum(swap_halves_add(pp1, pn1));
+  const float p2 = half_wave_sum(swap_halves_add(pp2, pn2));
+  __builtin_amdgcn_s_setprio(3);
+  const float2v start = spec_start32(p1, p2, j);
+  const float2v end = sg.chain(start);
+  bool hit;
+  float dist = spec_resolve_halves(start, end, j, &hit);
+  if (!hit) {
+    MMS_COUNT_MISS();
+    dist = chain_sum_lds(br ? sqn : sqp, ST4, 0.0f);
+  }
+  __builtin_amdgcn_s_setprio(0);
+  const float Tmine = 1.0f / (1.0f + sqrtf(dist));
+  const float Tp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tmine), 0));
+  const float Tn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tmine), 32));
+  if (lane == 0 && have) { s_pos[row] = Tp; s_neg[row] = Tn; }
+
+  // PairRankLoss on (Tp, Tn, y): every lane computes the same scalars
+  const PairTerm pt = pair_term(Tp, Tn, yy, margin);
+  float ga, gb;
+  pair_grad(yy, pt.ordered, pt.similar, s0, s1, ga, gb);
+  if (lane == 0 && have) partials[row] = pt.term;
+  if (!have) return;
+
+  float4* dq4 = reinterpret_cast<float4*>(dq) + base4;
+  float4* dp4 = reinterpret_cast<float4*>(dap) + base4;
+  float4* dn4 = reinterpret_cast<float4*>(dan) + base4;
+  float4 tp[NIT], tn[NIT];
+  if (EXACT) {
+    const EuclidCoef k0 = euclid_coef(Tp, ga), k1 = euclid_coef(Tn, gb);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) { tp[it] = euclid_tt4(k0, dp[it]); tn[it] = euclid_tt4(k1, dn[it]); }
+  } else {
+    const float c0 = ga * Tp * Tp * Tp, c1 = gb * Tn * Tn * Tn;
+    const float r0 = (float)rcp_newton((double)(Tp - 1.0f) + 1e-9);
+    const float r1 = (float)rcp_newton((double)(Tn - 1.0f) + 1e-9);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      tp[it].x = (c0 * dp[it].x) * r0; tp[it].y = (c0 * dp[it].y) * r0;
+      tp[it].z = (c0 * dp[it].z) * r0; tp[it].w = (c0 * dp[it].w) * r0;
+      tn[it].x = (c1 * dn[it].x) * r1; tn[it].y = (c1 * dn[it].y) * r1;
+      tn[it].z = (c1 * dn[it].z) * r1; tn[it].w = (c1 * dn[it].w) * r1;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if (!((it < NIT - 1) || last_ok)) break;
+    const int i = lane + 64 * it;
+    float4 oq, op, on;
+    oq.x = (0.f + tp[it].x) + (0.f + tn[it].x); oq.y = (0.f + tp[it].y) + (0.f + tn[it].y);
+    oq.z = (0.f + tp[it].z) + (0.f + tn[it].z); oq.w = (0.f + tp[it].w) + (0.f + tn[it].w);
+    op.x = 0.f + (-tp[it].x); op.y = 0.f + (-tp[it].y); op.z = 0.f + (-tp[it].z); op.w = 0.f + (-tp[it].w);
+    on.x = 0.f + (-tn[it].x); on.y = 0.f + (-tn[it].y); on.z = 0.f + (-tn[it].z); on.w = 0.f + (-tn[it].w);
+    stream_store(dq4 + i, oq);
+    stream_store(dp4 + i, op);
+    stream_store(dn4 + i, on);
+  }
+}
+
 // Generic fallback (any D / alignment): a workgroup owns ROWS triplets.
 template <int ROWS, int THREADS>
 __global__ __launch_bounds__(THREADS) void triplet_generic_kernel(
@@ -326,7 +464,23 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
   const bool v = (D % 4 == 0) && aligned16(q) && aligned16(ap) && aligned16(an) &&
                  aligned16(dq) && aligned16(dap) && aligned16(dan);
   int nparts;
-  if (v && D <= 1024) {
+  if (v && (D == 300 || D == 200 || D == 100)) {
+    constexpr int WPB = 8;
+    nparts = N;
+    const unsigned grid = (unsigned)((N + WPB - 1) / WPB);
+    const bool exact = euclid_backward_mode() == MMS_EUCLID_BWD_REFERENCE;
+#define MMS_T32(d4)                                                                               \
+  case 4 * d4:                                                                                    \
+    if (exact)                                                                                    \
+      hipLaunchKernelGGL((triplet32_kernel<d4, true, WPB>), dim3(grid), dim3(64 * WPB), 0, s, N,  \
+                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan);     \
+    else                                                                                          \
+      hipLaunchKernelGGL((triplet32_kernel<d4, false, WPB>), dim3(grid), dim3(64 * WPB), 0, s, N, \
+                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan);     \
+    break;
+    switch (D) { MMS_T32(25) MMS_T32(50) MMS_T32(75) }
+#undef MMS_T32
+  } else if (v && D <= 1024) {
     const int D4 = D / 4;
     const int nit = (D4 + 63) / 64;
     nparts = N;

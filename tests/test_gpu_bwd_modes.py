@@ -83,6 +83,38 @@ def test_fp32_mode_near_identical_pairs_and_extreme_scales(oracle, hiplib):
         assert np.abs(g[~normal].astype(np.float64) - dq_ref[~normal]).max() <= 1e-44
 
 
+@pytest.mark.parametrize("N,D", [(4096, 300), (13, 300), (257, 200), (64, 100)])
+def test_triplet_step_fp32_mode(N, D, oracle, hiplib):
+    """Fused (q, a+, a-) step in the default arithmetic: scores exact, gradients within 3 ulp of
+    the layer-by-layer oracle (dq is the sum of two branch terms, each within 1-2 ulp; compared
+    against the magnitude of the larger branch term, since the sum may cancel)."""
+    r = np.random.default_rng(N + D)
+    q = (r.standard_normal((N, 1, D)) * 0.4).astype(np.float32)
+    ap = (q + 0.04 * r.standard_normal((N, 1, D))).astype(np.float32)
+    an = (r.standard_normal((N, 1, D)) * 0.4).astype(np.float32)
+    y = (r.uniform(size=(N, 1)) < 0.8).astype(np.float32)
+    margin, lw = 0.05, 1.0
+    sp, _, _ = oracle.simcross_forward(1, q, ap)
+    sn, _, _ = oracle.simcross_forward(1, q, an)
+    loss_ref, o, s = oracle.pairrank_forward(sp.reshape(N, 1), sn.reshape(N, 1), y, margin)
+    gsp, gsn = oracle.pairrank_backward(y, o, s, top_diff=lw)
+    dq_p, dap_ref, _, _ = oracle.simcross_backward(1, q, ap, sp, gsp.reshape(sp.shape))
+    dq_n, dan_ref, _, _ = oracle.simcross_backward(1, q, an, sn, gsn.reshape(sn.shape))
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    out = dict(s_pos=torch.empty(N, 1, device="cuda"), s_neg=torch.empty(N, 1, device="cuda"),
+               loss=torch.empty(1, device="cuda"), dq=torch.empty(N, 1, D, device="cuda"),
+               da_pos=torch.empty(N, 1, D, device="cuda"), da_neg=torch.empty(N, 1, D, device="cuda"))
+    capi.set_euclid_backward_mode("fp32")
+    capi.triplet_euclid_step(d(q), d(ap), d(an), d(y), margin=margin, loss_weight=lw, **out)
+    h = {k: v.cpu().numpy() for k, v in out.items()}
+    assert (h["s_pos"].ravel().view(np.uint32) == sp.ravel().view(np.uint32)).all()
+    assert (h["s_neg"].ravel().view(np.uint32) == sn.ravel().view(np.uint32)).all()
+    assert abs(h["loss"][0] - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref))
+    assert _ulps(h["da_pos"], dap_ref).max() <= 2 and _ulps(h["da_neg"], dan_ref).max() <= 2
+    scale = np.maximum(np.abs(dq_p), np.abs(dq_n))
+    assert (np.abs(h["dq"] - (dq_p + dq_n)) <= 4 * np.spacing(scale)).all()
+
+
 def test_mode_setter_validates(hiplib):
     assert hiplib.mms_set_euclid_backward_mode(7) == 1            # MMS_ERR_INVALID_ARG
     capi.set_euclid_backward_mode("reference")

@@ -394,7 +394,8 @@ def test_pairrank(cfg, oracle, hiplib):
 # --------------------------------------------------------------------------- #
 # Fused (q, a+, a-) step == layer-by-layer oracle
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("cfg", [(8, 300), (4096, 300), (77, 301), (5, 4), (19, 1024), (7, 400)])
+@pytest.mark.parametrize("cfg", [(8, 300), (4096, 300), (4091, 300), (1, 300), (77, 301), (5, 4), (19, 1024), (7, 400),
+                                 (33, 200), (9, 100), (1000, 100)])
 def test_triplet_step(cfg, oracle, hiplib):
     from mms_answer_selection_amd import capi
     N, D = cfg
