@@ -270,6 +270,40 @@ size_t mms_embed_workspace_bytes(int M, int N);
 int mms_feed_gather_rows_f32(int rows, int row_elems, int src_rows, const float* src, const int* perm,
                              int first, float* dst, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * double instantiation.  The reference instantiates every layer for float and
+ * double (INSTANTIATE_CLASS, include/caffe/common.hpp:41-44); these are what a
+ * Layer<double>::Forward_gpu / Backward_gpu binds.  Same argument meaning and
+ * error behaviour as the _f32 functions above (no norm / workspace differences
+ * except that SimMatrix backward and PairRankLoss need no workspace).  The
+ * kernels are functional rather than tuned (csrc/f64_paths.hip); Euclidean
+ * results, PairRankLoss (loss included) and dbias are bit-identical to the CPU
+ * code, BLAS-backed results agree to ~1e-12.
+ * ------------------------------------------------------------------------- */
+size_t mms_simcross_workspace_bytes_f64(int dist_mode, int N, int W1, int W2, int D, int M);
+int mms_simcross_forward_f64(int dist_mode, int N, int W1, int W2, int D, int M, const double* q,
+                             const double* a, const double* W, const double* bias, double* top,
+                             double* norm0, double* norm1, void* workspace, size_t workspace_bytes,
+                             void* stream);
+int mms_simcross_backward_f64(int dist_mode, int N, int W1, int W2, int D, int M, const double* q,
+                              const double* a, const double* W, int bias_term, const double* top,
+                              const double* top_diff, const double* norm0, const double* norm1,
+                              int propagate_down0, int propagate_down1, double* dq, double* da,
+                              double* dW, double* dbias, void* workspace, size_t workspace_bytes,
+                              void* stream);
+int mms_simmatrix_forward_f64(int N, int K1, int K2, const double* q, const double* a,
+                              const double* W, double* top, double* qw_scratch, void* stream);
+int mms_simmatrix_backward_f64(int N, int K1, int K2, const double* q, const double* a,
+                               const double* W, const double* top_diff, int param_propagate_down,
+                               int propagate_down0, int propagate_down1, double* dq, double* da,
+                               double* dW, void* stream);
+int mms_pairrank_forward_f64(int count, double margin, const double* a, const double* b,
+                             const double* y, double* ordered, double* similar, double* loss,
+                             void* stream);
+int mms_pairrank_backward_f64(int count, double top_diff, const double* y, const double* ordered,
+                              const double* similar, int propagate_down0, int propagate_down1,
+                              double* da, double* db, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

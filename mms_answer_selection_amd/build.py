@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmms_hip.so")
 LAYER_LIB = os.path.join(HERE, "libmms_caffe.so")
 
-HIP_SOURCES = ["mms_abi.hip", "simcross_elementwise.hip", "bilinear.hip", "pairrank.hip", "ranking.hip", "embed.hip"]
+HIP_SOURCES = ["mms_abi.hip", "simcross_elementwise.hip", "bilinear.hip", "pairrank.hip", "ranking.hip", "embed.hip", "f64_paths.hip"]
 HIP_HEADERS = ["mms_common.h", "euclid_math.h"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

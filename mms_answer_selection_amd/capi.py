@@ -38,6 +38,13 @@ _SIGNATURES = {
     "mms_embed_forward_f32": (_i, [_i, _i, _i] + [_vp] * 5),
     "mms_embed_backward_f32": (_i, [_i, _i, _i] + [_vp] * 5 + [_sz, _vp]),
     "mms_feed_gather_rows_f32": (_i, [_i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "mms_simcross_workspace_bytes_f64": (_sz, [_i] * 6),
+    "mms_simcross_forward_f64": (_i, [_i] * 6 + [_vp] * 8 + [_sz, _vp]),
+    "mms_simcross_backward_f64": (_i, [_i] * 6 + [_vp] * 3 + [_i] + [_vp] * 4 + [_i, _i] + [_vp] * 5 + [_sz, _vp]),
+    "mms_simmatrix_forward_f64": (_i, [_i] * 3 + [_vp] * 6),
+    "mms_simmatrix_backward_f64": (_i, [_i] * 3 + [_vp] * 4 + [_i] * 3 + [_vp] * 4),
+    "mms_pairrank_forward_f64": (_i, [_i, C.c_double] + [_vp] * 7),
+    "mms_pairrank_backward_f64": (_i, [_i, C.c_double] + [_vp] * 3 + [_i, _i] + [_vp] * 3),
     "mms_set_euclid_backward_mode": (_i, [_i]),
     "mms_get_euclid_backward_mode": (_i, []),
     "mms_rank_workspace_bytes": (_sz, [_i]),
@@ -289,3 +296,67 @@ def set_euclid_backward_mode(mode):
 
 def get_euclid_backward_mode():
     return "reference" if lib().mms_get_euclid_backward_mode() == 1 else "fp32"
+
+
+# ---- double instantiation (functional kernels; tests/test_gpu_f64.py) -------------------------
+_D = torch.float64
+
+
+def simcross_forward_f64(mode, q, a, top, W=None, bias=None, norm0=None, norm1=None, ws=None):
+    N, W1, D = q.shape
+    W2 = a.shape[1]
+    M = W.shape[0] if mode == 2 else 1
+    wsp, wsb = (ws or _default_ws).get(lib().mms_simcross_workspace_bytes_f64(mode, N, W1, W2, D, M), q.device)
+    check(lib().mms_simcross_forward_f64(
+        mode, N, W1, W2, D, M, _ptr(q, "q", dtype=_D), _ptr(a, "a", dtype=_D), _ptr(W, "W", True, _D),
+        _ptr(bias, "bias", True, _D), _ptr(top, "top", dtype=_D), _ptr(norm0, "norm0", True, _D),
+        _ptr(norm1, "norm1", True, _D), wsp, wsb, _stream()), "mms_simcross_forward_f64")
+
+
+def simcross_backward_f64(mode, q, a, top, top_diff, dq, da, W=None, bias_term=False, norm0=None,
+                          norm1=None, dW=None, dbias=None, propagate_down=(True, True), ws=None):
+    N, W1, D = q.shape
+    W2 = a.shape[1]
+    M = W.shape[0] if mode == 2 else 1
+    wsp, wsb = (ws or _default_ws).get(lib().mms_simcross_workspace_bytes_f64(mode, N, W1, W2, D, M), q.device)
+    check(lib().mms_simcross_backward_f64(
+        mode, N, W1, W2, D, M, _ptr(q, "q", dtype=_D), _ptr(a, "a", dtype=_D), _ptr(W, "W", True, _D),
+        int(bool(bias_term)), _ptr(top, "top", dtype=_D), _ptr(top_diff, "top_diff", dtype=_D),
+        _ptr(norm0, "norm0", True, _D), _ptr(norm1, "norm1", True, _D), int(bool(propagate_down[0])),
+        int(bool(propagate_down[1])), _ptr(dq, "dq", dtype=_D), _ptr(da, "da", dtype=_D),
+        _ptr(dW, "dW", True, _D), _ptr(dbias, "dbias", True, _D), wsp, wsb, _stream()),
+        "mms_simcross_backward_f64")
+
+
+def simmatrix_forward_f64(q, a, W, top, qw_scratch):
+    N = q.shape[0]
+    K1, K2 = W.shape
+    check(lib().mms_simmatrix_forward_f64(
+        N, K1, K2, _ptr(q, "q", dtype=_D), _ptr(a, "a", dtype=_D), _ptr(W, "W", dtype=_D),
+        _ptr(top, "top", dtype=_D), _ptr(qw_scratch, "qw_scratch", dtype=_D), _stream()),
+        "mms_simmatrix_forward_f64")
+
+
+def simmatrix_backward_f64(q, a, W, top_diff, dq, da, dW, param_propagate_down=True,
+                           propagate_down=(True, True)):
+    N = q.shape[0]
+    K1, K2 = W.shape
+    check(lib().mms_simmatrix_backward_f64(
+        N, K1, K2, _ptr(q, "q", dtype=_D), _ptr(a, "a", dtype=_D), _ptr(W, "W", dtype=_D),
+        _ptr(top_diff, "top_diff", dtype=_D), int(bool(param_propagate_down)),
+        int(bool(propagate_down[0])), int(bool(propagate_down[1])), _ptr(dq, "dq", True, _D),
+        _ptr(da, "da", True, _D), _ptr(dW, "dW", True, _D), _stream()), "mms_simmatrix_backward_f64")
+
+
+def pairrank_forward_f64(a, b, y, ordered, similar, loss, margin=1.0):
+    check(lib().mms_pairrank_forward_f64(
+        a.numel(), float(margin), _ptr(a, "a", dtype=_D), _ptr(b, "b", dtype=_D), _ptr(y, "y", dtype=_D),
+        _ptr(ordered, "ordered", dtype=_D), _ptr(similar, "similar", dtype=_D),
+        _ptr(loss, "loss", dtype=_D), _stream()), "mms_pairrank_forward_f64")
+
+
+def pairrank_backward_f64(y, ordered, similar, da, db, top_diff=1.0, propagate_down=(True, True)):
+    check(lib().mms_pairrank_backward_f64(
+        y.numel(), float(top_diff), _ptr(y, "y", dtype=_D), _ptr(ordered, "ordered", dtype=_D),
+        _ptr(similar, "similar", dtype=_D), int(bool(propagate_down[0])), int(bool(propagate_down[1])),
+        _ptr(da, "da", True, _D), _ptr(db, "db", True, _D), _stream()), "mms_pairrank_backward_f64")

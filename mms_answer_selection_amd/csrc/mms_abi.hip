@@ -60,6 +60,24 @@ int embed_backward(int M, int N, int K, const float* index, const float* top_dif
                    float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes, hipStream_t s);
 int euclid_backward_mode();
 void set_euclid_backward_mode(int m);
+// f64_paths.hip
+size_t simcross_workspace_bytes_f64(int mode, int N, int W1, int W2, int D, int M);
+int simcross_forward_f64(int mode, int N, int W1, int W2, int D, int M, const double* q, const double* a,
+                         const double* W, const double* bias, double* top, double* norm0, double* norm1,
+                         void* ws, size_t ws_bytes, hipStream_t s);
+int simcross_backward_f64(int mode, int N, int W1, int W2, int D, int M, const double* q, const double* a,
+                          const double* W, int bias_term, const double* top, const double* top_diff,
+                          const double* norm0, const double* norm1, int pd0, int pd1, double* dq, double* da,
+                          double* dW, double* dbias, void* ws, size_t ws_bytes, hipStream_t s);
+int simmatrix_forward_f64(int N, int K1, int K2, const double* q, const double* a, const double* W,
+                          double* top, double* scratch, hipStream_t s);
+int simmatrix_backward_f64(int N, int K1, int K2, const double* q, const double* a, const double* W,
+                           const double* top_diff, int ppd, int pd0, int pd1, double* dq, double* da,
+                           double* dW, hipStream_t s);
+int pairrank_forward_f64(int count, double margin, const double* a, const double* b, const double* y,
+                         double* ordered, double* similar, double* loss, hipStream_t s);
+int pairrank_backward_f64(int count, double top_diff, const double* y, const double* ordered,
+                          const double* similar, double* da, double* db, hipStream_t s);
 int feed_gather_rows(int rows, int row_elems, int src_rows, const float* src, const int* perm, int first,
                      float* dst, hipStream_t s);
 }  // namespace mms
@@ -316,5 +334,79 @@ int mms_set_euclid_backward_mode(int mode) {
   return MMS_OK;
 }
 int mms_get_euclid_backward_mode(void) { return euclid_backward_mode(); }
+
+// ---- double instantiation (csrc/f64_paths.hip): same contracts as the _f32 entry points ----
+size_t mms_simcross_workspace_bytes_f64(int dist_mode, int N, int W1, int W2, int D, int M) {
+  if (!dims_ok(dist_mode, N, W1, W2, D, M)) return 0;
+  return simcross_workspace_bytes_f64(dist_mode, N, W1, W2, D, M);
+}
+
+int mms_simcross_forward_f64(int dist_mode, int N, int W1, int W2, int D, int M, const double* q,
+                             const double* a, const double* W, const double* bias, double* top,
+                             double* norm0, double* norm1, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  if (!dims_ok(dist_mode, N, W1, W2, D, M)) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q || !a || !top) return MMS_ERR_INVALID_ARG;
+  if (dist_mode == 0 && (!norm0 || !norm1)) return MMS_ERR_INVALID_ARG;
+  if (dist_mode == 2 && !W) return MMS_ERR_INVALID_ARG;
+  return simcross_forward_f64(dist_mode, N, W1, W2, D, M, q, a, W, bias, top, norm0, norm1, workspace,
+                              workspace_bytes, as_stream(stream));
+}
+
+int mms_simcross_backward_f64(int dist_mode, int N, int W1, int W2, int D, int M, const double* q,
+                              const double* a, const double* W, int bias_term, const double* top,
+                              const double* top_diff, const double* norm0, const double* norm1,
+                              int propagate_down0, int propagate_down1, double* dq, double* da,
+                              double* dW, double* dbias, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  if (!dims_ok(dist_mode, N, W1, W2, D, M)) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q || !a || !top || !top_diff || !dq || !da) return MMS_ERR_INVALID_ARG;
+  if (dist_mode == 0 && (!norm0 || !norm1)) return MMS_ERR_INVALID_ARG;
+  if (dist_mode == 2 && (!W || !dW || (bias_term && !dbias))) return MMS_ERR_INVALID_ARG;
+  return simcross_backward_f64(dist_mode, N, W1, W2, D, M, q, a, W, bias_term, top, top_diff, norm0,
+                               norm1, propagate_down0, propagate_down1, dq, da, dW, dbias, workspace,
+                               workspace_bytes, as_stream(stream));
+}
+
+int mms_simmatrix_forward_f64(int N, int K1, int K2, const double* q, const double* a,
+                              const double* W, double* top, double* qw_scratch, void* stream) {
+  if (N < 0 || K1 <= 0 || K2 <= 0) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q || !a || !W || !top || !qw_scratch) return MMS_ERR_INVALID_ARG;
+  return simmatrix_forward_f64(N, K1, K2, q, a, W, top, qw_scratch, as_stream(stream));
+}
+
+int mms_simmatrix_backward_f64(int N, int K1, int K2, const double* q, const double* a,
+                               const double* W, const double* top_diff, int param_propagate_down,
+                               int propagate_down0, int propagate_down1, double* dq, double* da,
+                               double* dW, void* stream) {
+  if (N < 0 || K1 <= 0 || K2 <= 0) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q || !a || !W || !top_diff) return MMS_ERR_INVALID_ARG;
+  if ((param_propagate_down && !dW) || (propagate_down0 && !dq) || (propagate_down1 && !da))
+    return MMS_ERR_INVALID_ARG;
+  return simmatrix_backward_f64(N, K1, K2, q, a, W, top_diff, param_propagate_down, propagate_down0,
+                                propagate_down1, dq, da, dW, as_stream(stream));
+}
+
+int mms_pairrank_forward_f64(int count, double margin, const double* a, const double* b,
+                             const double* y, double* ordered, double* similar, double* loss,
+                             void* stream) {
+  if (count <= 0) return MMS_ERR_INVALID_ARG;
+  if (!a || !b || !y || !ordered || !similar || !loss) return MMS_ERR_INVALID_ARG;
+  return pairrank_forward_f64(count, margin, a, b, y, ordered, similar, loss, as_stream(stream));
+}
+
+int mms_pairrank_backward_f64(int count, double top_diff, const double* y, const double* ordered,
+                              const double* similar, int propagate_down0, int propagate_down1,
+                              double* da, double* db, void* stream) {
+  if (count <= 0) return MMS_ERR_INVALID_ARG;
+  if (!y || !ordered || !similar) return MMS_ERR_INVALID_ARG;
+  if ((propagate_down0 && !da) || (propagate_down1 && !db)) return MMS_ERR_INVALID_ARG;
+  return pairrank_backward_f64(count, top_diff, y, ordered, similar, propagate_down0 ? da : nullptr,
+                               propagate_down1 ? db : nullptr, as_stream(stream));
+}
 
 }  // extern "C"
