@@ -219,15 +219,20 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
 
   float4 ra[FSL], rb[FSL];
   float sc[FSL];
+  bool la[FSL], lb[FSL];                       // was the slot inside the matrix?
 #pragma unroll
   for (int sl = 0; sl < FSL; ++sl) sc[sl] = 1.f;
+  // Out-of-range slots load from a valid address (the operand's base) and are zeroed when they
+  // are WRITTEN TO LDS.  `cond ? *p : zero` instead makes the compiler select between p and the
+  // address of a private zero: flat loads through scratch, each followed by vmcnt(0) -- nothing
+  // stays in flight behind the MFMAs.
   auto load = [&](int k0) {
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int sl = 0; sl < FSL; ++sl) {
-      ra[sl] = (a_ok[sl] && k0 + ak[sl] < kend) ? *reinterpret_cast<const float4*>(pa[sl]) : z4;
-      const bool bv = b_ok[sl] && k0 + bk[sl] < kend;
-      rb[sl] = bv ? *reinterpret_cast<const float4*>(pb[sl]) : z4;
+      la[sl] = a_ok[sl] && k0 + ak[sl] < kend;
+      lb[sl] = b_ok[sl] && k0 + bk[sl] < kend;
+      ra[sl] = *reinterpret_cast<const float4*>(la[sl] ? pa[sl] : A);
+      rb[sl] = *reinterpret_cast<const float4*>(lb[sl] ? pb[sl] : B);
       // the scale is only FETCHED here (clamped index, no dependent use): multiplying now
       // would put a vmcnt(0) wait in front of the MFMAs and drain the prefetch
       if (KSCALE) sc[sl] = ksc[min(k0 + bk[sl], g.K - 1)];
@@ -238,8 +243,11 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
   auto store = [&](int buf) {
     float* As = As2[buf];
     float* Bs = Bs2[buf];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int sl = 0; sl < FSL; ++sl) {
+      if (!la[sl]) ra[sl] = z4;
+      if (!lb[sl]) rb[sl] = z4;
       if (A_KVEC) {
         *reinterpret_cast<float4*>(&As[ai[sl] * LSK + ak[sl]]) = ra[sl];
       } else {
