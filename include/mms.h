@@ -56,7 +56,8 @@ const char* mms_error_string(int code);
  *   MMS_EUCLID_BWD_FP32 (default): fp32 throughout, tt = (c*(q-a)) * fl32(1/den);
  *       at most 2 ulp from the reference's value (<= 1.2e-7 relative; the bar is
  *       1e-5).  Used by the kernels specialised for D = 100 / 200 / 300 in the
- *       one-word geometry; every other kernel always runs the reference mode.
+ *       one-word geometry (SimCross and the fused triplet step) and by the tiled
+ *       word-grid backward; every other kernel always runs the reference mode.
  *   MMS_EUCLID_BWD_REFERENCE: the reference's bits, everywhere.
  * Process-wide; may also be chosen with the environment variable
  * MMS_EUCLID_BWD=reference|fp32 read at the first Euclidean launch.

@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256) void cross_bwd_kernel(
 // held to 1e-5 like everything that is BLAS-ordered in the reference.
 constexpr int kBwdDC = 32;
 
-template <int MODE>
+template <int MODE, bool EXACT>
 __global__ __launch_bounds__(256) void cross_bwd_tiled_kernel(
     const float* __restrict__ q, const float* __restrict__ a,
     const float* __restrict__ top, const float* __restrict__ top_diff,
@@ -822,6 +822,9 @@ __global__ __launch_bounds__(256) void cross_bwd_tiled_kernel(
   float* t_b2 = fbase + 3 * JK;                   // MODE 0: T/n1^2
   float* qs = fbase + (MODE == 1 ? JK : 4 * JK);
   float* as = qs + W1 * LS;
+  // fp32 backward arithmetic (include/mms.h): the double tables are not needed; fl32(1/den)
+  // lives in their place
+  float* t_r = reinterpret_cast<float*>(lds_d);
 
   const float* qn = q + (size_t)n * W1 * D;
   const float* an = a + (size_t)n * W2 * D;
@@ -831,7 +834,8 @@ __global__ __launch_bounds__(256) void cross_bwd_tiled_kernel(
   for (int e = threadIdx.x; e < JK; e += 256) {
     if (MODE == 1) {
       const EuclidCoef k = euclid_coef(Tn[e], gn[e]);
-      t_c[e] = k.c; t_den[e] = k.den; t_rcp[e] = k.rcp;
+      t_c[e] = k.c;
+      if (EXACT) { t_den[e] = k.den; t_rcp[e] = k.rcp; } else { t_r[e] = (float)k.rcp; }
     } else {
       const int j = e / W2, kk = e - j * W2;
       const float n0 = norm0[(size_t)n * W1 + j], n1 = norm1[(size_t)n * W2 + kk];
@@ -861,10 +865,12 @@ __global__ __launch_bounds__(256) void cross_bwd_tiled_kernel(
     for (int k = 0; k < W2; ++k) {
       const int t = j * W2 + k;
       const float av = as[k * LS + dd];
-      if (MODE == 1) {
+      if (MODE == 1 && EXACT) {
         EuclidCoef kc;
         kc.c = t_c[t]; kc.den = t_den[t]; kc.rcp = t_rcp[t];
         acc += euclid_tt(kc, qv - av);
+      } else if (MODE == 1) {
+        acc += (t_c[t] * (qv - av)) * t_r[t];
       } else {
         acc += t_c[t] * (av * t_i01[t] - qv * t_b1[t]);
       }
@@ -879,10 +885,12 @@ __global__ __launch_bounds__(256) void cross_bwd_tiled_kernel(
     for (int j = 0; j < W1; ++j) {
       const int t = j * W2 + k;
       const float qv = qs[j * LS + dd];
-      if (MODE == 1) {
+      if (MODE == 1 && EXACT) {
         EuclidCoef kc;
         kc.c = t_c[t]; kc.den = t_den[t]; kc.rcp = t_rcp[t];
         acc += -euclid_tt(kc, qv - av);
+      } else if (MODE == 1) {
+        acc += -((t_c[t] * (qv - av)) * t_r[t]);
       } else {
         acc += t_c[t] * (qv * t_i01[t] - av * t_b2[t]);
       }
@@ -1086,11 +1094,14 @@ int simcross_elementwise_backward(int mode, int N, int W1, int W2, int D,
     const size_t lds = cross_bwd_tiled_lds(mode, W1, W2);
     const int split = ((long long)N * nchunks < 1024) ? 1 : 0;     // fill the chip when the batch is small
     const unsigned grid = (unsigned)((split ? 2LL : 1LL) * N * nchunks);
-    if (mode == 1)
-      hipLaunchKernelGGL((cross_bwd_tiled_kernel<1>), dim3(grid), dim3(256), lds, s, q, a, top,
+    if (mode == 1 && euclid_backward_mode() == MMS_EUCLID_BWD_REFERENCE)
+      hipLaunchKernelGGL((cross_bwd_tiled_kernel<1, true>), dim3(grid), dim3(256), lds, s, q, a, top,
+                         top_diff, nullptr, nullptr, dq, da, W1, W2, D, nchunks, split);
+    else if (mode == 1)
+      hipLaunchKernelGGL((cross_bwd_tiled_kernel<1, false>), dim3(grid), dim3(256), lds, s, q, a, top,
                          top_diff, nullptr, nullptr, dq, da, W1, W2, D, nchunks, split);
     else
-      hipLaunchKernelGGL((cross_bwd_tiled_kernel<0>), dim3(grid), dim3(256), lds, s, q, a, top,
+      hipLaunchKernelGGL((cross_bwd_tiled_kernel<0, true>), dim3(grid), dim3(256), lds, s, q, a, top,
                          top_diff, norm0, norm1, dq, da, W1, W2, D, nchunks, split);
   } else if (mode == 1) {
     hipLaunchKernelGGL((cross_bwd_kernel<1>), dim3(N), dim3(256), 0, s, q, a, top, top_diff,

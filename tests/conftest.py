@@ -22,6 +22,15 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _build_before_anything_loads():
+    """Bring both shared libraries up to date BEFORE any test dlopens one of them: a rebuild of
+    libmms_hip.so after libmms_caffe.so has mapped the old file would leave two copies of the
+    library (and of its process-wide settings) in the process."""
+    from mms_answer_selection_amd import build
+    build.build_all()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import cpu_oracle

@@ -115,6 +115,42 @@ def test_triplet_step_fp32_mode(N, D, oracle, hiplib):
     assert (np.abs(h["dq"] - (dq_p + dq_n)) <= 4 * np.spacing(scale)).all()
 
 
+@pytest.mark.parametrize("shape", [(50, 40, 40, 50), (7, 40, 40, 300), (3, 5, 9, 33)])
+def test_cross_geometry_fp32_mode(shape, oracle, hiplib):
+    """Word-grid geometry (W1 x W2 scores per pair): scores exact; each gradient element is a sum of
+    W terms that are each within 2 ulp, so it is held to the north-star bar against the largest
+    magnitude, and to 4 ulp of the sum of the terms' magnitudes."""
+    N, W1, W2, D = shape
+    r = np.random.default_rng(sum(shape))
+    q = (r.standard_normal((N, W1, D)) * 0.4).astype(np.float32)
+    a = (r.standard_normal((N, W2, D)) * 0.4).astype(np.float32)
+    dT = r.standard_normal((N, 1, W1, W2)).astype(np.float32)
+    top_ref, _, _ = oracle.simcross_forward(1, q, a)
+    dq_ref, da_ref, _, _ = oracle.simcross_backward(1, q, a, top_ref, dT)
+    # magnitude budget: sum_k |tt| in float64
+    T = top_ref.astype(np.float64)[:, 0]
+    coef = np.abs(dT.astype(np.float64)[:, 0] * T ** 3 / (T - 1 + 1e-9))          # (N, W1, W2)
+    diff = np.abs(q.astype(np.float64)[:, :, None, :] - a.astype(np.float64)[:, None, :, :])
+    mag_q = (coef[..., None] * diff).sum(axis=2)
+    mag_a = (coef[..., None] * diff).sum(axis=1)
+    qd, ad, dTd = (torch.from_numpy(x).cuda() for x in (q, a, dT))
+    capi.set_euclid_backward_mode("fp32")
+    top = torch.empty(N, 1, W1, W2, device="cuda")
+    capi.simcross_forward(1, qd, ad, top)
+    assert (top.cpu().numpy().view(np.uint32) == top_ref.view(np.uint32)).all()
+    dq, da = torch.empty_like(qd), torch.empty_like(ad)
+    capi.simcross_backward(1, qd, ad, top, dTd, dq, da)
+    g, h = dq.cpu().numpy(), da.cpu().numpy()
+    eps = np.finfo(np.float32).eps
+    assert (np.abs(g - dq_ref) <= 4 * eps * mag_q + 1e-30).all()
+    assert (np.abs(h - da_ref) <= 4 * eps * mag_a + 1e-30).all()
+    np.testing.assert_allclose(g, dq_ref, rtol=0, atol=1e-5 * max(1.0, np.abs(dq_ref).max()))
+    capi.set_euclid_backward_mode("reference")
+    capi.simcross_backward(1, qd, ad, top, dTd, dq, da)
+    assert (dq.cpu().numpy().view(np.uint32) == dq_ref.view(np.uint32)).all()
+    assert (da.cpu().numpy().view(np.uint32) == da_ref.view(np.uint32)).all()
+
+
 def test_mode_setter_validates(hiplib):
     assert hiplib.mms_set_euclid_backward_mode(7) == 1            # MMS_ERR_INVALID_ARG
     capi.set_euclid_backward_mode("reference")

@@ -117,7 +117,7 @@ def test_euclid_shape_fuzz_bitexact(oracle, hiplib):
         assert_bitexact(host(ga2), da_ref, what + " da (two calls)")
 
 
-@pytest.mark.parametrize("D", [300, 1024])
+@pytest.mark.parametrize("D", [200, 300, 1024])
 def test_euclid_speculation_miss_falls_back_exactly(D, oracle, hiplib):
     """Adversarial rows for the speculative chain (euclid_math.h): one large square
     followed by squares below half an ulp of the running sum.  The sequential fp32
