@@ -110,9 +110,23 @@ def cpu_baseline(seconds):
     t1 = O.time_simcross_fwd_bwd(1, q, a, dT, iters=2) / 2          # warm-up + estimate
     iters = max(3, min(2000, int(seconds / max(t1, 1e-6))))
     t = O.time_simcross_fwd_bwd(1, q, a, dT, iters=iters)
-    return {"value": N_PAIRS * iters / t, "unit": "pairs/s", "cores": 1, "kind": "port",
-            "sample": "%d fwd+bwd passes of SimCross Euclid (4096,1,300) fp32, oracle/mms_oracle.c "
-                      "-O2 single thread, %.1f s on %d-cpu host" % (iters, t, os.cpu_count() or 0)}
+    out = {"value": N_PAIRS * iters / t, "unit": "pairs/s", "cores": 1, "kind": "port",
+           "sample": "%d fwd+bwd passes of SimCross Euclid (4096,1,300) fp32, oracle/mms_oracle.c "
+                     "-O2 single thread, %.1f s on %d-cpu host" % (iters, t, os.cpu_count() or 0)}
+    # courtesy upper bound: the same loops with the pairs dealt to the cores this
+    # process may use; the reference layer itself is single-threaded
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, 16))           # a one-GPU box's share of the host
+    if ncores > 1:
+        it_mt = max(8, min(20000, int(iters * ncores * 0.5)))
+        O.time_simcross_fwd_bwd_mt(1, q, a, dT, iters=4, threads=ncores)
+        tm = O.time_simcross_fwd_bwd_mt(1, q, a, dT, iters=it_mt, threads=ncores)
+        out["all_cores"] = {"value": N_PAIRS * it_mt / tm, "unit": "pairs/s", "cores": ncores,
+                            "sample": "%d passes, OpenMP over pairs, %.1f s" % (it_mt, tm)}
+    return out
 
 
 def load_traffic(path_name):

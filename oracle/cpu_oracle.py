@@ -240,3 +240,21 @@ def embed_backward(index, top_diff, weight_diff_in, bias_diff_in=None):
     getattr(lib(), "oracle_embed_backward" + sfx)(int(index.size), int(wd.shape[1]), _p(index),
                                                   _p(top_diff), _p(wd), _p(bd))
     return wd, bd
+
+
+def time_simcross_fwd_bwd_mt(mode, q, a, top_diff, iters=1, threads=1):
+    """Seconds for `iters` fwd+bwd passes with the pairs dealt to `threads` OpenMP threads
+    (modes 0 / 1; courtesy upper bound next to the single-threaded reference loop)."""
+    dt = np.float32
+    q, a, top_diff = _c(q, dt), _c(a, dt), _c(top_diff, dt)
+    N, W1, D = q.shape
+    W2 = a.shape[1]
+    top = np.zeros((N, 1, W1, W2), dt)
+    n0 = np.zeros((N, W1), dt)
+    n1 = np.zeros((N, W2), dt)
+    dq = np.zeros_like(q)
+    da = np.zeros_like(a)
+    f = lib().oracle_time_simcross_fwd_bwd_mt_f32
+    f.restype = C.c_double
+    return f(C.c_int(mode), N, W1, W2, D, _p(q), _p(a), _p(top_diff), _p(top), _p(n0), _p(n1),
+             _p(dq), _p(da), int(iters), int(threads))

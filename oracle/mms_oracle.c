@@ -86,3 +86,33 @@ double oracle_time_simcross_fwd_bwd_f32(int mode, int N, int W1, int W2, int D,
   clock_gettime(CLOCK_MONOTONIC, &t1);
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* The same loop with the pairs dealt to `threads` OpenMP threads in contiguous slices
+ * (modes 0 and 1 only: no shared parameter gradients).  The reference layer is single
+ * threaded; this is the courtesy upper bound SURVEY 8(d) asks for next to it, labelled
+ * as such by bench.py.  Every slice runs the unmodified per-pair loops above. */
+double oracle_time_simcross_fwd_bwd_mt_f32(int mode, int N, int W1, int W2, int D,
+                                           const float* q, const float* a,
+                                           const float* top_diff, float* top,
+                                           float* norm0, float* norm1, float* dq,
+                                           float* da, int iters, int threads) {
+  struct timespec t0, t1;
+  if (threads < 1) threads = 1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int it = 0; it < iters; ++it) {
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int c = 0; c < threads; ++c) {
+      const int lo = (int)((long long)N * c / threads), hi = (int)((long long)N * (c + 1) / threads);
+      const int n = hi - lo;
+      if (n <= 0) continue;
+      const size_t oq = (size_t)lo * W1 * D, oa = (size_t)lo * W2 * D, ot = (size_t)lo * W1 * W2;
+      oracle_simcross_forward_f32(mode, n, W1, W2, D, 1, q + oq, a + oa, NULL, NULL, top + ot,
+                                  norm0 ? norm0 + (size_t)lo * W1 : NULL, norm1 ? norm1 + (size_t)lo * W2 : NULL);
+      oracle_simcross_backward_f32(mode, n, W1, W2, D, 1, q + oq, a + oa, NULL, 0, top + ot, top_diff + ot,
+                                   norm0 ? norm0 + (size_t)lo * W1 : NULL, norm1 ? norm1 + (size_t)lo * W2 : NULL,
+                                   1, 1, dq + oq, da + oa, NULL, NULL);
+    }
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
