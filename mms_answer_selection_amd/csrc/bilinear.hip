@@ -38,6 +38,7 @@ struct GemmArgs {
   const float* addend; long long ad_b1;    // optional C(i,j) += addend[i*ldc + j]
   const float* bkscale;                    // optional B(k,j) *= bkscale[k] on load (fast j-vector path)
   int beta_one;                            // C = result + C
+  int stream_c;                            // C is written once and not re-read soon: non-temporal stores
   int a_ifast, b_jfast;                    // which index is contiguous in memory
 };
 
@@ -306,8 +307,9 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
     if (rs) v = rs[gi] * v;
     if (ad) v = ad[gi * g.ldc + gj] + v;
     float* c = C + gi * g.ldc + gj;
-    if (g.beta_one) v = v + *c;
-    *c = v;
+    if (g.beta_one) { v = v + *c; *c = v; }
+    else if (g.stream_c) __builtin_nontemporal_store(v, c);
+    else *c = v;
   }
 }
 
@@ -615,12 +617,14 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
     // dq_j = dT_j * (W a_j)   (:88, NoTrans, beta 0)
     GemmArgs g = gemm_args(N, K1, K2, a, K2, 1, W, 1, K2, dq, K1);
     g.rowscale = top_diff;
+    g.stream_c = 1;                             // read next by another layer, not by this call
     gemm_launch(g, 1, s);
   }
   if (pd1) {
     // da_j = dT_j * (W^T q_j)   (:88, Trans, beta 0)
     GemmArgs g = gemm_args(N, K2, K1, q, K1, 1, W, K2, 1, da, K2);
     g.rowscale = top_diff;
+    g.stream_c = 1;                             // read next by another layer, not by this call
     gemm_launch(g, 1, s);
   }
   return launch_status();
