@@ -388,7 +388,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   const long long stride = (long long)gridDim.x * 256;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(long long)k * n + e];
+    // eight slabs requested before the first add (same s-ascending order; a load-add-load loop
+    // costs one memory round trip per slab)
+    for (int k0 = 0; k0 < splits; k0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(long long)min(k0 + u, splits - 1) * n + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (k0 + u < splits) ? v[u] : 0.f;
+    }
     out[e] = accumulate ? out[e] + s : s;
   }
 }
