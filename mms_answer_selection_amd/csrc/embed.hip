@@ -53,22 +53,157 @@ __global__ __launch_bounds__(256) void embed_keys_kernel(int M, int K, const flo
   vals[n] = (unsigned)n;
 }
 
-// One workgroup per sorted position; only the first position of each word id works:
-// it owns that destination row and adds the row's contributions in n order.
-__global__ __launch_bounds__(256) void embed_bwd_kernel(int M, int N, const unsigned* __restrict__ keys,
-                                                        const unsigned* __restrict__ vals,
-                                                        const float* __restrict__ top_diff,
-                                                        float* __restrict__ weight_diff) {
-  const int p = blockIdx.x;
+// heads[s] = first sorted position of the s-th distinct word id (rocprim::select over a
+// counting iterator with these flags); segment s is [heads[s], heads[s+1]) in (keys, vals).
+__global__ __launch_bounds__(256) void embed_head_flags_kernel(int M, const unsigned* __restrict__ keys,
+                                                               unsigned char* __restrict__ flags) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < M) flags[p] = (p == 0 || keys[p - 1] != keys[p]) ? 1 : 0;
+}
+
+// One workgroup per (word id, 64-column slice): it owns that destination row and adds the
+// id's rows in n order.  The adds are a dependent chain by definition (fp32, reference order),
+// so everything else is taken off it: wave 0 only adds, from LDS, eight reads ahead; the other
+// waves GATHER the next chunk of CH rows (row numbers staged through LDS one chunk further
+// ahead, then CH/8 independent loads per thread, all issued before the first LDS write).  One
+// memory round trip per chunk instead of two per row -- the zero-pad word id owns thousands
+// of rows of a TREC-QA batch.  Short segments (<= CH rows: nearly every id) are one chunk.
+template <int CH, int GW>   // GW gathering waves; block = 64 * (GW + 1) threads
+__global__ __launch_bounds__(64 * (GW + 1)) void embed_bwd_seg_kernel(
+    int M, int N, const unsigned* __restrict__ keys, const unsigned* __restrict__ vals,
+    const unsigned* __restrict__ heads, const unsigned* __restrict__ nseg,
+    const float* __restrict__ top_diff, float* __restrict__ weight_diff, int rmin, int rmax) {
+  extern __shared__ float seg_buf[];             // [2][CH][64] floats, then [2][CH] row numbers
+  constexpr int RPT = CH / GW;                   // rows per gathering thread per chunk
+  static_assert(CH % GW == 0, "chunk rows must divide evenly over the gathering waves");
+  unsigned* vbuf = reinterpret_cast<unsigned*>(seg_buf + 2 * CH * 64);
+  const int seg = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int count = (int)nseg[0];
+  if (seg >= count) return;
+  const int p = (int)heads[seg];
+  const int R = (seg + 1 < count ? (int)heads[seg + 1] : M) - p;
+  if (R < rmin || R > rmax) return;
   const unsigned idx = keys[p];
-  if (p > 0 && keys[p - 1] == idx) return;
-  float* w = weight_diff + (size_t)idx * N;
-  for (int d = threadIdx.x; d < N; d += 256) {
-    float acc = w[d];
-    for (int r = p; r < M && keys[r] == idx; ++r)
-      acc = 1.0f * top_diff[(size_t)vals[r] * N + d] + acc;      // caffe_axpy(alpha = 1)
-    w[d] = acc;
+  const int gt = tid - 64;                       // >= 0: a gathering thread
+  const int col = gt & 63, rg = gt >> 6, gcol = min(c0 + col, N - 1);
+  auto stage_rows = [&](int b, int r0) {         // row numbers of chunk [r0, r0 + CH) -> vbuf[b]
+    for (int e = gt; gt >= 0 && e < CH; e += 64 * GW) vbuf[b * CH + e] = vals[p + min(r0 + e, R - 1)];
+  };
+  auto gather = [&](int b, int r0) {             // rows rg, rg + GW, ... of the chunk, column `col`
+    if (gt < 0) return;
+    float x[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) x[u] = top_diff[(size_t)vbuf[b * CH + rg + u * GW] * N + gcol];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) seg_buf[(b * CH + rg + u * GW) * 64 + col] = x[u];
+  };
+  stage_rows(0, 0);
+  __syncthreads();
+  gather(0, 0);
+  if (CH < R) stage_rows(1, CH);
+  __syncthreads();
+  const bool adder = tid < 64 && c0 + tid < N;
+  float acc = adder ? weight_diff[(size_t)idx * N + c0 + tid] : 0.f;
+  for (int r0 = 0, b = 0; r0 < R; r0 += CH, b ^= 1) {
+    if (r0 + 2 * CH < R) stage_rows(b, r0 + 2 * CH);      // vbuf[b] was consumed before the last barrier
+    if (r0 + CH < R) gather(b ^ 1, r0 + CH);              // row numbers staged one iteration ago
+    if (adder) {
+      const int rows = min(CH, R - r0);
+      const float* colp = seg_buf + (size_t)b * CH * 64 + tid;
+      int row = 0;
+      for (; row + 8 <= rows; row += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = colp[(row + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = 1.0f * v[u] + acc;     // caffe_axpy(alpha = 1), n ascending
+      }
+      for (; row < rows; ++row) acc = 1.0f * colp[row * 64] + acc;
+    }
+    __syncthreads();                                        // chunk r0 + CH is in seg_buf[b ^ 1], its successor's rows in vbuf[b]
   }
+  if (adder) weight_diff[(size_t)idx * N + c0 + tid] = acc;
+}
+
+// Small batches (M <= 4096: the driver's 50 x 40-word training batch is 2,000 indices per Embed
+// layer): the whole inverted index -- clamp, stable radix sort of (id, n), head flags, compaction
+// of the head positions and their count -- in ONE workgroup and one launch instead of the dozen
+// launches of the device-wide sort + select (each a few microseconds of pure latency).
+constexpr int kPrepThreads = 1024, kPrepItems = 4, kPrepMax = kPrepThreads * kPrepItems;
+__global__ __launch_bounds__(kPrepThreads) void embed_prep_small_kernel(
+    int M, int K, unsigned bits, const float* __restrict__ index, unsigned* __restrict__ keys,
+    unsigned* __restrict__ vals, unsigned* __restrict__ heads, unsigned* __restrict__ nseg) {
+  using sort_t = rocprim::block_radix_sort<unsigned, kPrepThreads, kPrepItems, unsigned>;
+  using scan_t = rocprim::block_scan<unsigned, kPrepThreads>;
+  __shared__ union { typename sort_t::storage_type sort; typename scan_t::storage_type scan; } tmp;
+  __shared__ unsigned skeys[kPrepMax + 1];
+  const int t = threadIdx.x;
+  unsigned k[kPrepItems], v[kPrepItems];
+#pragma unroll
+  for (int i = 0; i < kPrepItems; ++i) {
+    const int n = t * kPrepItems + i;
+    int idx = n < M ? (int)index[n] : 0;
+    idx = idx < 0 ? 0 : (idx >= K ? K - 1 : idx);
+    k[i] = n < M ? (unsigned)idx : 0xffffffffu;  // padding sorts to the end (all `bits` + the pad bit)
+    v[i] = (unsigned)n;
+  }
+  sort_t().sort(k, v, tmp.sort, 0, bits + 1 > 32 ? 32 : bits + 1);   // stable: equal ids keep n ascending
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kPrepItems; ++i) {
+    const int pos = t * kPrepItems + i;
+    skeys[pos + 1] = k[i];
+    if (pos < M) { keys[pos] = k[i]; vals[pos] = v[i]; }
+  }
+  if (t == 0) skeys[0] = 0xfffffffeu;            // differs from every real id and from the padding
+  __syncthreads();
+  unsigned flag[kPrepItems], mine = 0;
+#pragma unroll
+  for (int i = 0; i < kPrepItems; ++i) {
+    const int pos = t * kPrepItems + i;
+    flag[i] = (pos < M && skeys[pos] != skeys[pos + 1]) ? 1u : 0u;
+    mine += flag[i];
+  }
+  unsigned before = 0, total = 0;
+  scan_t().exclusive_scan(mine, before, 0u, total, tmp.scan);
+#pragma unroll
+  for (int i = 0; i < kPrepItems; ++i) {
+    if (flag[i]) heads[before++] = (unsigned)(t * kPrepItems + i);
+  }
+  if (t == 0) nseg[0] = total;
+}
+
+// Short segments (nearly every word id: a handful of rows): one WAVE per (id, 64-column slice),
+// four per workgroup, no LDS and no barrier -- the row numbers and then the rows are requested
+// all at once (8 or 32 unconditional loads with clamped addresses), then added in order.
+__global__ __launch_bounds__(256) void embed_bwd_short_kernel(
+    int M, int N, const unsigned* __restrict__ keys, const unsigned* __restrict__ vals,
+    const unsigned* __restrict__ heads, const unsigned* __restrict__ nseg,
+    const float* __restrict__ top_diff, float* __restrict__ weight_diff) {
+  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int c = blockIdx.y * 64 + lane;
+  const int count = (int)nseg[0];
+  if (seg >= count) return;
+  const int p = (int)heads[seg];
+  const int R = (seg + 1 < count ? (int)heads[seg + 1] : M) - p;
+  if (R > 32) return;                            // embed_bwd_seg_kernel's
+  const unsigned idx = keys[p];
+  const int gc = min(c, N - 1);
+  float acc = weight_diff[(size_t)idx * N + gc];
+  if (R <= 8) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = top_diff[(size_t)vals[p + min(u, R - 1)] * N + gc];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (u < R) acc = 1.0f * x[u] + acc;
+  } else {
+    float x[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) x[u] = top_diff[(size_t)vals[p + min(u, R - 1)] * N + gc];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) if (u < R) acc = 1.0f * x[u] + acc;
+  }
+  if (c < N) weight_diff[(size_t)idx * N + c] = acc;
 }
 
 // bias_diff += column sums of top_diff (gemv in the reference: BLAS order, 1e-5 bar).
@@ -90,17 +225,24 @@ __global__ __launch_bounds__(256) void embed_bias_finish_kernel(int chunks, int 
   const int d = blockIdx.x * 256 + threadIdx.x;
   if (d >= N) return;
   float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * N + d];
+  for (int c0 = 0; c0 < chunks; c0 += 8) {       // eight loads in flight, same c-ascending order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)min(c0 + u, chunks - 1) * N + d];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (c0 + u < chunks) ? v[u] : 0.f;
+  }
   bias_diff[d] = 1.0f * s + 1.0f * bias_diff[d];
 }
 
-struct EmbedWs { size_t k0, k1, v0, v1, partial, temp, total; int chunks; };
+struct EmbedWs { size_t k0, k1, v0, v1, flags, heads, nseg, partial, temp, total; int chunks; };
 static EmbedWs embed_ws(int M, int N) {
   EmbedWs w{};
   size_t o = 0;
   auto take = [&](size_t b) { size_t at = o; o += round_up(b, 256); return at; };
   w.k0 = take((size_t)M * 4); w.k1 = take((size_t)M * 4);
   w.v0 = take((size_t)M * 4); w.v1 = take((size_t)M * 4);
+  w.flags = take((size_t)M); w.heads = take((size_t)M * 4); w.nseg = take(256);
   w.chunks = (M + kBiasChunk - 1) / kBiasChunk;
   w.partial = take((size_t)w.chunks * N * 4);
   w.temp = o;
@@ -126,16 +268,42 @@ int embed_backward(int M, int N, int K, const float* index, const float* top_dif
   auto* v0 = reinterpret_cast<unsigned*>(base + lay.v0);
   auto* v1 = reinterpret_cast<unsigned*>(base + lay.v1);
   if (weight_diff) {
-    hipLaunchKernelGGL(embed_keys_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, K, index,
-                       k0, v0);
-    size_t need = 0;
-    if (rocprim::radix_sort_pairs(nullptr, need, k0, k1, v0, v1, (size_t)M, 0u, 32u, s) != hipSuccess)
-      return MMS_ERR_LAUNCH;
-    if (lay.temp + need > ws_bytes) return MMS_ERR_WORKSPACE;
-    if (rocprim::radix_sort_pairs(base + lay.temp, need, k0, k1, v0, v1, (size_t)M, 0u, 32u, s) != hipSuccess)
-      return MMS_ERR_LAUNCH;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)M), dim3(256), 0, s, M, N, k1, v1, top_diff,
-                       weight_diff);
+    unsigned bits = 1;                              // keys are clamped to [0, K): sort those bits only
+    while (bits < 32 && (1ull << bits) < (unsigned long long)K) ++bits;
+    auto* heads = reinterpret_cast<unsigned*>(base + lay.heads);
+    auto* nseg = reinterpret_cast<unsigned*>(base + lay.nseg);
+    if (M <= kPrepMax && bits < 32) {
+      hipLaunchKernelGGL(embed_prep_small_kernel, dim3(1), dim3(kPrepThreads), 0, s, M, K, bits, index, k1, v1,
+                         heads, nseg);
+    } else {
+      hipLaunchKernelGGL(embed_keys_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, K, index,
+                         k0, v0);
+      size_t need = 0;
+      if (rocprim::radix_sort_pairs(nullptr, need, k0, k1, v0, v1, (size_t)M, 0u, bits, s) != hipSuccess)
+        return MMS_ERR_LAUNCH;
+      if (lay.temp + need > ws_bytes) return MMS_ERR_WORKSPACE;
+      if (rocprim::radix_sort_pairs(base + lay.temp, need, k0, k1, v0, v1, (size_t)M, 0u, bits, s) != hipSuccess)
+        return MMS_ERR_LAUNCH;
+      // distinct ids: head flags -> compacted head positions (+ their count, on the device)
+      auto* flags = reinterpret_cast<unsigned char*>(base + lay.flags);
+      hipLaunchKernelGGL(embed_head_flags_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, k1, flags);
+      size_t need2 = 0;
+      rocprim::counting_iterator<unsigned> pos(0);
+      if (rocprim::select(nullptr, need2, pos, flags, heads, nseg, (size_t)M, s) != hipSuccess) return MMS_ERR_LAUNCH;
+      if (lay.temp + need2 > ws_bytes) return MMS_ERR_WORKSPACE;
+      if (rocprim::select(base + lay.temp, need2, pos, flags, heads, nseg, (size_t)M, s) != hipSuccess)
+        return MMS_ERR_LAUNCH;
+    }
+    const dim3 grid((unsigned)std::min(M, K), (unsigned)((N + 63) / 64));   // at most min(M, K) distinct ids
+    constexpr size_t kLongLds = 2 * 256 * (64 * sizeof(float) + sizeof(unsigned));   // 130 KB of the CU's 160 KB
+    static const hipError_t once = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&embed_bwd_seg_kernel<256, 8>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLongLds);
+    (void)once;
+    hipLaunchKernelGGL(embed_bwd_short_kernel, dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, s, M, N, k1, v1,
+                       heads, nseg, top_diff, weight_diff);
+    hipLaunchKernelGGL((embed_bwd_seg_kernel<256, 8>), grid, dim3(576), kLongLds, s, M, N, k1, v1, heads, nseg,
+                       top_diff, weight_diff, 33, 0x7fffffff);
   }
   if (bias_diff) {
     float* partial = reinterpret_cast<float*>(base + lay.partial);
