@@ -79,40 +79,118 @@ __global__ __launch_bounds__(256) void rank_bucket_kernel(int n,
   flags[i] = fl;
 }
 
-// Folds the buckets in sorted (= ascending group id) order with the reference's
-// running sums.  One thread: n is an evaluation split (thousands), not a batch.
-__global__ void rank_fold_kernel(int n, const float* __restrict__ ap, const int* __restrict__ rank,
-                                 const int* __restrict__ flags, float* __restrict__ map_out,
-                                 float* __restrict__ mrr_out, int* __restrict__ effective) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// Folds the buckets in sorted (= ascending group id) order with the reference's running sums.
+// The sums are sequential by definition; ONE WAVE runs them so that the operands arrive 64
+// positions per coalesced load (four loads in flight) instead of one dependent load per
+// position: ballots pick the positions that carry a bucket result, and the wave-uniform
+// running sums are advanced in position order with v_readlane.
+__global__ __launch_bounds__(64) void rank_fold_kernel(int n, const float* __restrict__ ap,
+                                                       const int* __restrict__ rank,
+                                                       const int* __restrict__ flags,
+                                                       float* __restrict__ map_out,
+                                                       float* __restrict__ mrr_out,
+                                                       int* __restrict__ effective) {
+  const int lane = threadIdx.x;
   float map_ = 0.f, mrr = 0.f;
   int eff_map = 0, eff_mrr = 0;
-  for (int i = 0; i < n; ++i) {
-    const int fl = flags[i];
-    if (fl & 1) { ++eff_map; map_ += ap[i]; }                       // map_layer.cpp:93-94
-    // mrr += 1.0/(mrr_rank+1): float + double, stored back to float (mrr_layer.cpp:75)
-    if (fl & 2) { ++eff_mrr; mrr = (float)((double)mrr + 1.0 / (rank[i] + 1)); }
+  int nfl[4], nrk[4];
+  float na[4];
+  auto fetch = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 64 * u + lane, ic = i < n ? i : n - 1;
+      nfl[u] = flags[ic];
+      na[u] = ap[ic];
+      nrk[u] = rank[ic];
+    }
+  };
+  fetch(0);
+  for (int base = 0; base < n; base += 256) {
+    int fl[4], rk[4];
+    float a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      fl[u] = (base + 64 * u + lane < n) ? nfl[u] : 0;
+      a[u] = na[u];
+      rk[u] = nrk[u];
+    }
+    if (base + 256 < n) fetch(base + 256);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      unsigned long long m1 = __ballot(fl[u] & 1), m2 = __ballot(fl[u] & 2);
+      eff_map += __popcll(m1);
+      eff_mrr += __popcll(m2);
+      while (m1) {                                                   // map_layer.cpp:93-94
+        const int l = __ffsll((long long)m1) - 1;
+        m1 &= m1 - 1;
+        map_ += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[u]), l));
+      }
+      while (m2) {   // mrr += 1.0/(mrr_rank+1): float + double, stored back to float (mrr_layer.cpp:75)
+        const int l = __ffsll((long long)m2) - 1;
+        m2 &= m2 - 1;
+        mrr = (float)((double)mrr + 1.0 / (__builtin_amdgcn_readlane(rk[u], l) + 1));
+      }
+    }
   }
-  if (map_out) *map_out = map_ / eff_map;   // NaN when no bucket counts, like the reference (:99)
-  if (mrr_out) *mrr_out = mrr / eff_mrr;
-  if (effective) *effective = eff_map;
+  if (lane == 0) {
+    if (map_out) *map_out = map_ / eff_map;   // NaN when no bucket counts, like the reference (:99)
+    if (mrr_out) *mrr_out = mrr / eff_mrr;
+    if (effective) *effective = eff_map;
+  }
 }
 
-// AUC: global descending sort, then the reference's sequential walk (auc_layer.cpp:119-134).
-__global__ void auc_fold_kernel(int n, const unsigned* __restrict__ vals,
-                                const float* __restrict__ label, int has_ignore, int ignore_label,
-                                float* __restrict__ auc_out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// AUC: global descending sort, then the reference's sequential walk (auc_layer.cpp:119-134):
+//   high += lab; auc += high * (1 - lab)     (ints; the product is converted to float and added)
+// `high` is an integer prefix sum (exact in any order); the float running sum is the only
+// sequential part.  One wave: 64 sorted items per step, labels gathered through the sort
+// permutation four steps ahead, `high` by a wave scan, and the 64 terms added in item order
+// with compile-time-lane v_readlane (two instructions per item, one dependent add).
+__device__ __forceinline__ int wave_inclusive_scan_i32(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+__global__ __launch_bounds__(64) void auc_fold_kernel(int n, const unsigned* __restrict__ vals,
+                                                      const float* __restrict__ label, int has_ignore,
+                                                      int ignore_label, float* __restrict__ auc_out) {
+  const int lane = threadIdx.x;
   float auc = 0.f;
   int high = 0, count = 0;
-  for (int i = 0; i < n; ++i) {
-    const int lab = (int)label[vals[i]];
-    if (has_ignore && lab == ignore_label) continue;   // :68-70 (skipped items keep their order)
-    ++count;
-    high += lab;
-    auc += high * (1 - lab);
+  float nxt[4];
+  auto fetch = [&](int base) {                    // clamped addresses: unconditional loads
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 64 * u + lane;
+      nxt[u] = label[vals[i < n ? i : n - 1]];
+    }
+  };
+  fetch(0);
+  for (int base = 0; base < n; base += 256) {
+    int lab[4];
+    bool use[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 64 * u + lane;
+      lab[u] = (int)nxt[u];
+      use[u] = i < n && !(has_ignore && lab[u] == ignore_label);     // :68-70 (skipped items keep their order)
+      if (!use[u]) lab[u] = 0;
+    }
+    if (base + 256 < n) fetch(base + 256);        // in flight behind this block's 256 dependent adds
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int incl = high + wave_inclusive_scan_i32(lab[u], lane);
+      const float term = use[u] ? (float)(incl * (1 - lab[u])) : 0.f;   // skipped items add +0: exact (auc >= 0 ... or any)
+      count += __popcll(__ballot(use[u]));
+      high = __builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+      for (int l = 0; l < 64; ++l)
+        auc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(term), l));
+    }
   }
-  *auc_out = high > 0 ? auc / high / (count - high) : 0.f;
+  if (lane == 0) *auc_out = high > 0 ? auc / high / (count - high) : 0.f;
 }
 
 __global__ __launch_bounds__(256) void rank_accuracy_kernel(int count, const float* __restrict__ a,
