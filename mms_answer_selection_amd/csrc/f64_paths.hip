@@ -274,9 +274,16 @@ __global__ void d_pair_loss(int count, const double* __restrict__ y, const doubl
                             const double* __restrict__ similar, double* __restrict__ loss) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double l = 0;
-  for (int i = 0; i < count; ++i) {
-    const double o = ordered[i] > 0.0 ? ordered[i] : 0.0;
-    l += o + fabs((1 - y[i]) * similar[i]);
+  for (int i0 = 0; i0 < count; i0 += 8) {        // eight elements requested before the first add
+    double o[8], yy[8], sm[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(i0 + u, count - 1);
+      o[u] = ordered[i]; yy[u] = y[i]; sm[u] = similar[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u < count) l += (o[u] > 0.0 ? o[u] : 0.0) + fabs((1 - yy[u]) * sm[u]);
   }
   *loss = l / (double)count;
 }
