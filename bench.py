@@ -302,7 +302,9 @@ def run(args):
                                     "HBM-cold ring of %d batches (%.2f GiB)" % (ring, ring * 19.7e6 / 2**30),
                        "hip_graph_group": G if use_graph else 0,
                        "parallelism": "pair-sharded x%d%s" % (
-                           world, ", RCCL all-gather of scores per %d steps" % G if world > 1 else "")},
+                           world, ", %s all-gather of scores per %d steps" % (
+                               "RCCL" if args.backend == "nccl" else "host-staged gloo (rehearsal)", G)
+                           if world > 1 else "")},
         }
         if achieved is not None:
             out["roofline"] = {
