@@ -163,12 +163,17 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
 //     grid is 256 x 5 = 1280 workgroups = exactly 5 per CU (no tail).
 // FK = 16 measured faster than 32 at cfg 3 (43 vs 67 us for the 16384x300x300 product):
 // the shallower tile keeps more workgroups' loads in flight per CU.
-constexpr int FM = 64, FN = 64, FK = 16, LSK = FK + 4, LSJ = FN + 4;
-constexpr int FSL = FK / 16;     // float4 load slots per operand per thread per tile
-constexpr int FH = FK / 2;       // k values per half-wave per tile
+// The k-tile depth FK is a template parameter: 16 when several workgroups share a CU (cfg 3: their
+// MFMA phases cover each other's barriers), 32 when a product is so small that a CU holds one or
+// two workgroups and every tile boundary (LDS write -> barrier -> LDS read, ~0.3 us) is exposed --
+// half as many boundaries for the driver's 32 x 40 x 40 x 300 bilinear products.
+constexpr int FM = 64, FN = 64, LSJ = FN + 4;
 
-template <bool A_KVEC, bool B_JVEC, bool KSCALE>
+template <bool A_KVEC, bool B_JVEC, bool KSCALE, int FK>
 __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
+  constexpr int LSK = FK + 4;
+  constexpr int FSL = FK / 16;     // float4 load slots per operand per thread per tile
+  constexpr int FH = FK / 2;       // k values per half-wave per tile
   __shared__ float As2[2][FM * LSK];            // double-buffered: one barrier per k-tile
   __shared__ float Bs2[2][FK * LSJ];
   const int z = blockIdx.z;
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
 static bool mult4(long long x) { return (x & 3) == 0; }
 // which fast variant (if any) can run these arguments: 0 none, else 1 + 2*A_KVEC + B_JVEC
 static int gemm_fast_variant(const GemmArgs& g) {
-  if (g.kchunk % FK != 0 && g.ksplit > 1) return 0;
+  if (g.kchunk % 32 != 0 && g.ksplit > 1) return 0;   // split boundaries must fall on k-tile boundaries (16 or 32)
   if (g.bkscale && !(g.b_cs == 1)) return 0;
   const bool bases = aligned16(g.A) && aligned16(g.B) && mult4(g.a_b0) && mult4(g.a_b1) &&
                      mult4(g.b_b0) && mult4(g.b_b1);
@@ -361,18 +366,19 @@ static void gemm_launch(const GemmArgs& g0, int nb0, hipStream_t s) {
     if (fv) {
       dim3 grid((g.N + FN - 1) / FN, (g.M + FM - 1) / FM, nb * per_b0);
       const bool ksc = g.bkscale != nullptr;   // only with B_JVEC (gemm_fast_variant)
+      const bool deep = (long long)grid.x * grid.y * grid.z <= 2 * 256;   // at most two workgroups per CU
+#define MMS_FAST(a, b, c)                                                                              \
+  do {                                                                                                 \
+    if (deep) hipLaunchKernelGGL((gemm32_fast_kernel<a, b, c, 32>), grid, dim3(256), 0, s, g);         \
+    else hipLaunchKernelGGL((gemm32_fast_kernel<a, b, c, 16>), grid, dim3(256), 0, s, g);              \
+  } while (0)
       switch (fv - 1) {
-        case 0: hipLaunchKernelGGL((gemm32_fast_kernel<false, false, false>), grid, dim3(256), 0, s, g); break;
-        case 1:
-          if (ksc) hipLaunchKernelGGL((gemm32_fast_kernel<false, true, true>), grid, dim3(256), 0, s, g);
-          else hipLaunchKernelGGL((gemm32_fast_kernel<false, true, false>), grid, dim3(256), 0, s, g);
-          break;
-        case 2: hipLaunchKernelGGL((gemm32_fast_kernel<true, false, false>), grid, dim3(256), 0, s, g); break;
-        default:
-          if (ksc) hipLaunchKernelGGL((gemm32_fast_kernel<true, true, true>), grid, dim3(256), 0, s, g);
-          else hipLaunchKernelGGL((gemm32_fast_kernel<true, true, false>), grid, dim3(256), 0, s, g);
-          break;
+        case 0: MMS_FAST(false, false, false); break;
+        case 1: if (ksc) MMS_FAST(false, true, true); else MMS_FAST(false, true, false); break;
+        case 2: MMS_FAST(true, false, false); break;
+        default: if (ksc) MMS_FAST(true, true, true); else MMS_FAST(true, true, false); break;
       }
+#undef MMS_FAST
       continue;
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, nb * per_b0);
@@ -456,7 +462,7 @@ static int pick_ksplit(int Mt, int Nt, int K, int* kchunk) {
   if (want < 1) want = 1;
   if (want > 256) want = 256;
   int chunk = (int)((K + want - 1) / want);
-  chunk = (chunk + FK - 1) / FK * FK;
+  chunk = (chunk + 31) / 32 * 32;               // a multiple of either k-tile depth (16, 32)
   *kchunk = chunk;
   return (K + chunk - 1) / chunk;
 }
