@@ -61,6 +61,18 @@ void mms_caffe_set_random_seed(unsigned seed);
 /* Comma-separated registered layer types ("PairRankLoss,SimCross,SimMatrix"). */
 const char* mms_layer_registry_types(void);
 
+/* Layer<double> (the reference instantiates every layer for float and double, common.hpp:41-44):
+ * SimCross, SimMatrix and PairRankLoss are registered for double as well.  The handle API above is
+ * float; this one call creates a Layer<double> from prototxt, loads the bottoms (and optionally the
+ * parameter blobs) from host arrays, runs SetUp / Forward / Backward and copies out top[0], the
+ * bottom diffs and the parameter diffs (which start from the values passed in).  top_diff == NULL
+ * means a loss layer (diff 1).  Returns 0, or non-zero with a message in err. */
+int mms_layer_run_f64(const char* prototxt, int nbottom, const int* bottom_axes, const int* bottom_dims,
+                      const double* const* bottom_data, int nparam, const double* const* param_data,
+                      const double* top_diff, const int* propagate_down, double* top_out, long long top_capacity,
+                      int* top_dims_out, int* top_axes_out, double* const* bottom_diff_out,
+                      double* const* param_diff_out, char* err, int err_len);
+
 /* ------------------------------------------------------------------------- *
  * .caffemodel snapshots (binary NetParameter).  Host-only
  * except the two *_layer functions, which touch Blob memory.

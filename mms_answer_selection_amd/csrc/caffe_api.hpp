@@ -512,8 +512,8 @@ class LayerRegisterer {
   }
 };
 
-// Only float is instantiated: the HIP kernels are fp32 (the reference also
-// instantiates double, common.hpp:41-44 -- listed as open in DESIGN.md).
+// float for every layer; float AND double (common.hpp:41-44) for the three layers of the path,
+// whose C ABI has _f64 entry points (the *_FD macros below).
 #define REGISTER_LAYER_CREATOR(type, creator) \
   static LayerRegisterer<float> g_creator_f_##type(#type, creator<float>)
 #define REGISTER_LAYER_CLASS(type)                                                    \
@@ -523,6 +523,12 @@ class LayerRegisterer {
   }                                                                                   \
   REGISTER_LAYER_CREATOR(type, Creator_##type##Layer)
 #define INSTANTIATE_CLASS(classname) template class classname<float>
+#define REGISTER_LAYER_CLASS_FD(type)                                                 \
+  REGISTER_LAYER_CLASS(type);                                                         \
+  static LayerRegisterer<double> g_creator_d_##type(#type, Creator_##type##Layer<double>)
+#define INSTANTIATE_CLASS_FD(classname) \
+  template class classname<float>;      \
+  template class classname<double>
 
 }  // namespace caffe
 #endif  // MMS_CAFFE_API_HPP_

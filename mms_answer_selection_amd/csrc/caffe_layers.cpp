@@ -83,10 +83,71 @@ Filler<Dtype>* GetFiller(const FillerParameter& param) {
   return nullptr;
 }
 template Filler<float>* GetFiller<float>(const FillerParameter&);
+template Filler<double>* GetFiller<double>(const FillerParameter&);
 
 static void mms_check(int rc, const char* what) {
   CHECK_EQ(rc, (int)MMS_OK) << what << ": " << mms_error_string(rc);
 }
+// The C ABI by element type: what lets one layer template serve Layer<float> and Layer<double>.
+namespace abi {
+inline size_t simcross_ws(float, int mode, int N, int W1, int W2, int D, int M) { return mms_simcross_workspace_bytes(mode, N, W1, W2, D, M); }
+inline size_t simcross_ws(double, int mode, int N, int W1, int W2, int D, int M) { return mms_simcross_workspace_bytes_f64(mode, N, W1, W2, D, M); }
+inline int simcross_forward(int mode, int N, int W1, int W2, int D, int M, const float* q, const float* a, const float* W,
+                            const float* bias, float* top, float* n0, float* n1, void* ws, size_t wsb) {
+  return mms_simcross_forward_f32(mode, N, W1, W2, D, M, q, a, W, bias, top, n0, n1, ws, wsb, nullptr);
+}
+inline int simcross_forward(int mode, int N, int W1, int W2, int D, int M, const double* q, const double* a, const double* W,
+                            const double* bias, double* top, double* n0, double* n1, void* ws, size_t wsb) {
+  return mms_simcross_forward_f64(mode, N, W1, W2, D, M, q, a, W, bias, top, n0, n1, ws, wsb, nullptr);
+}
+inline int simcross_backward(int mode, int N, int W1, int W2, int D, int M, const float* q, const float* a, const float* W,
+                             int bias_term, const float* top, const float* dT, const float* n0, const float* n1, int pd0,
+                             int pd1, float* dq, float* da, float* dW, float* db, void* ws, size_t wsb) {
+  return mms_simcross_backward_f32(mode, N, W1, W2, D, M, q, a, W, bias_term, top, dT, n0, n1, pd0, pd1, dq, da, dW, db, ws,
+                                   wsb, nullptr);
+}
+inline int simcross_backward(int mode, int N, int W1, int W2, int D, int M, const double* q, const double* a, const double* W,
+                             int bias_term, const double* top, const double* dT, const double* n0, const double* n1, int pd0,
+                             int pd1, double* dq, double* da, double* dW, double* db, void* ws, size_t wsb) {
+  return mms_simcross_backward_f64(mode, N, W1, W2, D, M, q, a, W, bias_term, top, dT, n0, n1, pd0, pd1, dq, da, dW, db, ws,
+                                   wsb, nullptr);
+}
+inline size_t simmatrix_ws(float, int N, int K1, int K2) { return mms_simmatrix_workspace_bytes(N, K1, K2); }
+inline size_t simmatrix_ws(double, int, int, int) { return 0; }
+inline int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, const float* W, float* top, float* scr) {
+  return mms_simmatrix_forward_f32(N, K1, K2, q, a, W, top, scr, nullptr);
+}
+inline int simmatrix_forward(int N, int K1, int K2, const double* q, const double* a, const double* W, double* top, double* scr) {
+  return mms_simmatrix_forward_f64(N, K1, K2, q, a, W, top, scr, nullptr);
+}
+inline int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, const float* W, const float* dT, int ppd,
+                              int pd0, int pd1, float* dq, float* da, float* dW, void* ws, size_t wsb) {
+  return mms_simmatrix_backward_f32(N, K1, K2, q, a, W, dT, ppd, pd0, pd1, dq, da, dW, ws, wsb, nullptr);
+}
+inline int simmatrix_backward(int N, int K1, int K2, const double* q, const double* a, const double* W, const double* dT,
+                              int ppd, int pd0, int pd1, double* dq, double* da, double* dW, void*, size_t) {
+  return mms_simmatrix_backward_f64(N, K1, K2, q, a, W, dT, ppd, pd0, pd1, dq, da, dW, nullptr);
+}
+inline size_t pairrank_ws(float, int count) { return mms_pairrank_workspace_bytes(count); }
+inline size_t pairrank_ws(double, int) { return 0; }
+inline int pairrank_forward(int count, float margin, const float* a, const float* b, const float* y, float* o, float* s,
+                            float* loss, void* ws, size_t wsb) {
+  return mms_pairrank_forward_f32(count, margin, a, b, y, o, s, loss, ws, wsb, nullptr);
+}
+inline int pairrank_forward(int count, double margin, const double* a, const double* b, const double* y, double* o, double* s,
+                            double* loss, void*, size_t) {
+  return mms_pairrank_forward_f64(count, margin, a, b, y, o, s, loss, nullptr);
+}
+inline int pairrank_backward(int count, float td, const float* y, const float* o, const float* s, int pd0, int pd1, float* da,
+                             float* db) {
+  return mms_pairrank_backward_f32(count, td, y, o, s, pd0, pd1, da, db, nullptr);
+}
+inline int pairrank_backward(int count, double td, const double* y, const double* o, const double* s, int pd0, int pd1,
+                             double* da, double* db) {
+  return mms_pairrank_backward_f64(count, td, y, o, s, pd0, pd1, da, db, nullptr);
+}
+}  // namespace abi
+
 #define NO_CPU_MODE MMS_FATAL("") << this->type() << " Layer: libmms is the GPU (HIP) implementation; " \
   "CPU mode is served by the reference's own Forward_cpu/Backward_cpu, not by this library."
 
@@ -132,8 +193,8 @@ class SimCrossLayer : public Layer<Dtype> {
       data0_norm_.Reshape(vector<int>{bottom[0]->num(), bottom[0]->channels()});
       data1_norm_.Reshape(vector<int>{bottom[1]->num(), bottom[1]->channels()});
     }
-    const size_t ws = mms_simcross_workspace_bytes(dist_mode_, bottom[0]->num(), bottom[0]->channels(),
-                                                   bottom[1]->channels(), bottom[0]->height(), M);
+    const size_t ws = abi::simcross_ws(Dtype(0), dist_mode_, bottom[0]->num(), bottom[0]->channels(),
+                                       bottom[1]->channels(), bottom[0]->height(), M);
     if (ws) workspace_.Reshape(vector<int>{(int)((ws + sizeof(Dtype) - 1) / sizeof(Dtype))});
   }
 
@@ -145,7 +206,7 @@ class SimCrossLayer : public Layer<Dtype> {
   void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
     const int M = top[0]->channels();
     const bool mode2 = dist_mode_ == 2, mode0 = dist_mode_ == 0;
-    mms_check(mms_simcross_forward_f32(
+    mms_check(abi::simcross_forward(
                   dist_mode_, bottom[0]->num(), bottom[0]->channels(), bottom[1]->channels(),
                   bottom[0]->height(), M, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
                   mode2 ? this->blobs_[0]->gpu_data() : nullptr,
@@ -153,8 +214,8 @@ class SimCrossLayer : public Layer<Dtype> {
                   top[0]->mutable_gpu_data(), mode0 ? data0_norm_.mutable_gpu_data() : nullptr,
                   mode0 ? data1_norm_.mutable_gpu_data() : nullptr,
                   workspace_.count() ? workspace_.mutable_gpu_data() : nullptr,
-                  (size_t)workspace_.count() * sizeof(Dtype), nullptr),
-              "mms_simcross_forward_f32");
+                  (size_t)workspace_.count() * sizeof(Dtype)),
+              "mms_simcross_forward");
   }
 
   // replaces sim_cross_layer.cpp:166-307 / sim_cross_layer.cu:197-243
@@ -163,7 +224,7 @@ class SimCrossLayer : public Layer<Dtype> {
     const int M = top[0]->channels();
     const bool mode2 = dist_mode_ == 2, mode0 = dist_mode_ == 0;
     const bool bias_term = mode2 && this->blobs_.size() > 1;
-    mms_check(mms_simcross_backward_f32(
+    mms_check(abi::simcross_backward(
                   dist_mode_, bottom[0]->num(), bottom[0]->channels(), bottom[1]->channels(),
                   bottom[0]->height(), M, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
                   mode2 ? this->blobs_[0]->gpu_data() : nullptr, bias_term, top[0]->gpu_data(),
@@ -173,16 +234,16 @@ class SimCrossLayer : public Layer<Dtype> {
                   mode2 ? this->blobs_[0]->mutable_gpu_diff() : nullptr,
                   bias_term ? this->blobs_[1]->mutable_gpu_diff() : nullptr,
                   workspace_.count() ? workspace_.mutable_gpu_data() : nullptr,
-                  (size_t)workspace_.count() * sizeof(Dtype), nullptr),
-              "mms_simcross_backward_f32");
+                  (size_t)workspace_.count() * sizeof(Dtype)),
+              "mms_simcross_backward");
   }
 
   int dist_mode_ = 1;  // 1 euclid, 0 cosine, 2 bilinear (sim_cross_layer.hpp:36)
   Blob<Dtype> data0_norm_, data1_norm_;
   Blob<Dtype> workspace_;  // replaces measure_temp{0,1}_
 };
-INSTANTIATE_CLASS(SimCrossLayer);
-REGISTER_LAYER_CLASS(SimCross);
+INSTANTIATE_CLASS_FD(SimCrossLayer);
+REGISTER_LAYER_CLASS_FD(SimCross);
 
 // ===================================== SimMatrix =============================
 // Reference: include/caffe/layers/sim_matrix_layer.hpp, src/caffe/layers/sim_matrix_layer.cpp
@@ -216,7 +277,7 @@ class SimMatrixLayer : public Layer<Dtype> {
     CHECK_EQ(K2_, bottom[1]->count(1)) << "Input size incompatible with inner product parameters.";
     M_ = bottom[0]->count(0, 1);
     top[0]->Reshape(vector<int>{bottom[0]->shape(0), 1});
-    const size_t ws = mms_simmatrix_workspace_bytes(M_, K1_, K2_);
+    const size_t ws = abi::simmatrix_ws(Dtype(0), M_, K1_, K2_);
     workspace_.Reshape(vector<int>{(int)((ws + sizeof(Dtype) - 1) / sizeof(Dtype))});
   }
 
@@ -226,29 +287,30 @@ class SimMatrixLayer : public Layer<Dtype> {
 
   // replaces sim_matrix_layer.cpp:53-65; Q*W lands in bottom[1]'s diff, as in the reference (:58)
   void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
-    mms_check(mms_simmatrix_forward_f32(M_, K1_, K2_, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
-                                        this->blobs_[0]->gpu_data(), top[0]->mutable_gpu_data(),
-                                        bottom[1]->mutable_gpu_diff(), nullptr),
-              "mms_simmatrix_forward_f32");
+    mms_check(abi::simmatrix_forward(M_, K1_, K2_, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
+                                     this->blobs_[0]->gpu_data(), top[0]->mutable_gpu_data(),
+                                     bottom[1]->mutable_gpu_diff()),
+              "mms_simmatrix_forward");
   }
   // replaces sim_matrix_layer.cpp:68-95
   void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down,
                     const vector<Blob<Dtype>*>& bottom) override {
     const bool ppd = this->param_propagate_down_[0];
-    mms_check(mms_simmatrix_backward_f32(
+    mms_check(abi::simmatrix_backward(
                   M_, K1_, K2_, bottom[0]->gpu_data(), bottom[1]->gpu_data(), this->blobs_[0]->gpu_data(),
                   top[0]->gpu_diff(), ppd, propagate_down[0], propagate_down[1],
                   propagate_down[0] ? bottom[0]->mutable_gpu_diff() : nullptr,
                   propagate_down[1] ? bottom[1]->mutable_gpu_diff() : nullptr,
-                  ppd ? this->blobs_[0]->mutable_gpu_diff() : nullptr, workspace_.mutable_gpu_data(),
-                  (size_t)workspace_.count() * sizeof(Dtype), nullptr),
-              "mms_simmatrix_backward_f32");
+                  ppd ? this->blobs_[0]->mutable_gpu_diff() : nullptr,
+                  workspace_.count() ? workspace_.mutable_gpu_data() : nullptr,
+                  (size_t)workspace_.count() * sizeof(Dtype)),
+              "mms_simmatrix_backward");
   }
   int K1_ = 0, K2_ = 0, M_ = 0;
   Blob<Dtype> workspace_;
 };
-INSTANTIATE_CLASS(SimMatrixLayer);
-REGISTER_LAYER_CLASS(SimMatrix);
+INSTANTIATE_CLASS_FD(SimMatrixLayer);
+REGISTER_LAYER_CLASS_FD(SimMatrix);
 
 // ================================ LossLayer / PairRankLoss ===================
 // Reference: include/caffe/layers/loss_layer.hpp:22-49, src/caffe/layers/loss_layer.cpp:8-23
@@ -291,7 +353,7 @@ class PairRankLossLayer : public LossLayer<Dtype> {
     margin_ = (Dtype)this->layer_param_.pair_rank_loss_param().margin();
     ordered_diff_.Reshape(bottom[0]->num(), bottom[0]->channels(), 1, 1);
     similar_diff_.Reshape(bottom[0]->num(), bottom[0]->channels(), 1, 1);
-    const size_t ws = mms_pairrank_workspace_bytes(ordered_diff_.count());
+    const size_t ws = abi::pairrank_ws(Dtype(0), ordered_diff_.count());
     if (ws) workspace_.Reshape(vector<int>{(int)((ws + sizeof(Dtype) - 1) / sizeof(Dtype))});
   }
 
@@ -303,30 +365,30 @@ class PairRankLossLayer : public LossLayer<Dtype> {
   void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
     const int count = bottom[0]->count();
     CHECK_LE(count, ordered_diff_.count()) << "PairRankLoss caches are sized in LayerSetUp; batch grew";
-    mms_check(mms_pairrank_forward_f32(count, margin_, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
-                                       bottom[2]->gpu_data(), ordered_diff_.mutable_gpu_data(),
-                                       similar_diff_.mutable_gpu_data(), top[0]->mutable_gpu_data(),
-                                       workspace_.count() ? workspace_.mutable_gpu_data() : nullptr,
-                                       (size_t)workspace_.count() * sizeof(Dtype), nullptr),
-              "mms_pairrank_forward_f32");
+    mms_check(abi::pairrank_forward(count, margin_, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
+                                    bottom[2]->gpu_data(), ordered_diff_.mutable_gpu_data(),
+                                    similar_diff_.mutable_gpu_data(), top[0]->mutable_gpu_data(),
+                                    workspace_.count() ? workspace_.mutable_gpu_data() : nullptr,
+                                    (size_t)workspace_.count() * sizeof(Dtype)),
+              "mms_pairrank_forward");
   }
   // replaces pair_rank_loss_layer.cpp:55-84 (CPU semantics: strict '>')
   void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down,
                     const vector<Blob<Dtype>*>& bottom) override {
     if (propagate_down[2]) LOG_FATAL << this->type() << " Layer cannot backpropagate to label inputs.";
     if (!propagate_down[0] && !propagate_down[1]) return;
-    mms_check(mms_pairrank_backward_f32(bottom[0]->count(), top[0]->cpu_diff()[0], bottom[2]->gpu_data(),
-                                        ordered_diff_.gpu_data(), similar_diff_.gpu_data(),
-                                        propagate_down[0], propagate_down[1],
-                                        propagate_down[0] ? bottom[0]->mutable_gpu_diff() : nullptr,
-                                        propagate_down[1] ? bottom[1]->mutable_gpu_diff() : nullptr, nullptr),
-              "mms_pairrank_backward_f32");
+    mms_check(abi::pairrank_backward(bottom[0]->count(), top[0]->cpu_diff()[0], bottom[2]->gpu_data(),
+                                     ordered_diff_.gpu_data(), similar_diff_.gpu_data(),
+                                     propagate_down[0], propagate_down[1],
+                                     propagate_down[0] ? bottom[0]->mutable_gpu_diff() : nullptr,
+                                     propagate_down[1] ? bottom[1]->mutable_gpu_diff() : nullptr),
+              "mms_pairrank_backward");
   }
   Dtype margin_ = 1;
   Blob<Dtype> ordered_diff_, similar_diff_, workspace_;
 };
-INSTANTIATE_CLASS(PairRankLossLayer);
-REGISTER_LAYER_CLASS(PairRankLoss);
+INSTANTIATE_CLASS_FD(PairRankLossLayer);
+REGISTER_LAYER_CLASS_FD(PairRankLoss);
 
 // ======================================= Embed ===============================
 // Reference: include/caffe/layers/embed_layer.hpp, src/caffe/layers/embed_layer.cpp (the fork
@@ -1130,6 +1192,61 @@ void mms_h5_writer_add(mms_h5_writer_t* w, const char* name, const long long* di
 int mms_h5_writer_save(const mms_h5_writer_t* w, const char* path, char* err, int err_len) {
   std::string e;
   if (!mms_h5::WriteContiguous(path, w->sets, &e)) { set_err(err, err_len, e); return 1; }
+  return 0;
+}
+
+// ---- Layer<double>: one-shot run (create by type string, SetUp, Forward, Backward) ----
+// The handle API above is float; this single entry point drives the double instantiation of the
+// three path layers end to end so that it can be checked against the oracle's double code.
+int mms_layer_run_f64(const char* prototxt, int nbottom, const int* bottom_axes, const int* bottom_dims,
+                      const double* const* bottom_data, int nparam, const double* const* param_data,
+                      const double* top_diff, const int* propagate_down, double* top_out, long long top_capacity,
+                      int* top_dims_out, int* top_axes_out, double* const* bottom_diff_out,
+                      double* const* param_diff_out, char* err, int err_len) {
+  caffe::LayerParameter lp;
+  std::string e;
+  if (!prototxt || !caffe::ReadLayerParameterFromText(prototxt, &lp, &e)) { set_err(err, err_len, e); return 1; }
+  if (caffe::LayerRegistry<double>::Registry().count(lp.type()) == 0) {
+    set_err(err, err_len, "no Layer<double> registered for type " + lp.type());
+    return 2;
+  }
+  std::shared_ptr<caffe::Layer<double> > layer = caffe::LayerRegistry<double>::CreateLayer(lp);
+  std::vector<std::unique_ptr<caffe::Blob<double> > > bots;
+  std::vector<caffe::Blob<double>*> bottom, top;
+  int at = 0;
+  for (int b = 0; b < nbottom; ++b) {
+    std::vector<int> shape(bottom_dims + at, bottom_dims + at + bottom_axes[b]);
+    at += bottom_axes[b];
+    bots.emplace_back(new caffe::Blob<double>(shape));
+    std::memcpy(bots.back()->mutable_cpu_data(), bottom_data[b], sizeof(double) * bots.back()->count());
+    bottom.push_back(bots.back().get());
+  }
+  caffe::Blob<double> top0;
+  top.push_back(&top0);
+  layer->SetUp(bottom, top);
+  if ((int)layer->blobs().size() != nparam && nparam != 0) { set_err(err, err_len, "parameter blob count mismatch"); return 3; }
+  for (int i = 0; i < nparam; ++i)
+    if (param_data && param_data[i])
+      std::memcpy(layer->blobs()[i]->mutable_cpu_data(), param_data[i], sizeof(double) * layer->blobs()[i]->count());
+  layer->Forward(bottom, top);
+  if (top0.count() > top_capacity) { set_err(err, err_len, "top buffer too small"); return 4; }
+  std::memcpy(top_out, top0.cpu_data(), sizeof(double) * top0.count());
+  *top_axes_out = top0.num_axes();
+  for (int a = 0; a < top0.num_axes() && a < 8; ++a) top_dims_out[a] = top0.shape(a);
+  if (top_diff) std::memcpy(top0.mutable_cpu_diff(), top_diff, sizeof(double) * top0.count());
+  else top0.mutable_cpu_diff()[0] = 1.0;                        // a loss layer's loss_weight
+  std::vector<bool> pd(nbottom);
+  for (int b = 0; b < nbottom; ++b) pd[b] = propagate_down ? propagate_down[b] != 0 : true;
+  for (int i = 0; i < nparam; ++i)                                // start the parameter diffs from the caller's values
+    if (param_diff_out && param_diff_out[i])
+      std::memcpy(layer->blobs()[i]->mutable_cpu_diff(), param_diff_out[i], sizeof(double) * layer->blobs()[i]->count());
+  layer->Backward(top, pd, bottom);
+  for (int b = 0; b < nbottom; ++b)
+    if (bottom_diff_out && bottom_diff_out[b])
+      std::memcpy(bottom_diff_out[b], bottom[b]->cpu_diff(), sizeof(double) * bottom[b]->count());
+  for (int i = 0; i < nparam; ++i)
+    if (param_diff_out && param_diff_out[i])
+      std::memcpy(param_diff_out[i], layer->blobs()[i]->cpu_diff(), sizeof(double) * layer->blobs()[i]->count());
   return 0;
 }
 

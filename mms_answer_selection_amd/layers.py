@@ -45,6 +45,8 @@ _SIGNATURES = {
     "mms_caffe_set_mode": (None, [_i]),
     "mms_caffe_set_random_seed": (None, [C.c_uint]),
     "mms_layer_registry_types": (C.c_char_p, []),
+    "mms_layer_run_f64": (_i, [C.c_char_p, _i, _ip, _ip, _vp, _i, _vp, _vp, _ip, _vp, C.c_longlong, _ip, _ip, _vp, _vp,
+                               C.c_char_p, _i]),
     "mms_h5_open": (_vp, [C.c_char_p, C.c_char_p, _i]),
     "mms_h5_close": (None, [_vp]),
     "mms_h5_num_datasets": (_i, [_vp]),
@@ -402,3 +404,35 @@ def write_h5(path, datasets):
             raise IOError(err.value.decode())
     finally:
         lib().mms_h5_writer_destroy(w)
+
+
+def run_layer_f64(prototxt, bottoms, top_diff=None, params=None, param_diffs=None, propagate_down=None,
+                  top_capacity=1 << 22):
+    """Layer<double> end to end (include/mms_layer.h: mms_layer_run_f64): returns
+    (top, [bottom diffs], [parameter diffs]) as float64 arrays."""
+    f = lib().mms_layer_run_f64
+    dp = C.POINTER(C.c_double)
+    bots = [np.ascontiguousarray(b, np.float64) for b in bottoms]
+    axes = (C.c_int * len(bots))(*[b.ndim for b in bots])
+    dims = [d for b in bots for d in b.shape]
+    dims_c = (C.c_int * max(1, len(dims)))(*dims)
+    bptr = (dp * len(bots))(*[b.ctypes.data_as(dp) for b in bots])
+    params = [np.ascontiguousarray(p, np.float64) for p in (params or [])]
+    pdiffs = [np.array(d, np.float64, copy=True) for d in (param_diffs or [np.zeros_like(p) for p in params])]
+    pptr = (dp * max(1, len(params)))(*[p.ctypes.data_as(dp) for p in params])
+    pdptr = (dp * max(1, len(params)))(*[d.ctypes.data_as(dp) for d in pdiffs])
+    bdiffs = [np.full(b.shape, np.nan) for b in bots]
+    bdptr = (dp * len(bots))(*[d.ctypes.data_as(dp) for d in bdiffs])
+    td = None if top_diff is None else np.ascontiguousarray(top_diff, np.float64)
+    pd = None if propagate_down is None else (C.c_int * len(bots))(*[1 if x else 0 for x in propagate_down])
+    top = np.empty(top_capacity, np.float64)
+    tdims, taxes = (C.c_int * 8)(), C.c_int(0)
+    err = C.create_string_buffer(512)
+    rc = f(prototxt.encode(), len(bots), axes, dims_c, bptr, len(params), pptr,
+           None if td is None else td.ctypes.data_as(dp), pd, top.ctypes.data_as(dp), C.c_longlong(top_capacity),
+           tdims, C.byref(taxes), bdptr, pdptr, err, 512)
+    if rc:
+        raise RuntimeError("mms_layer_run_f64: %s (code %d)" % (err.value.decode(), rc))
+    shape = tuple(tdims[a] for a in range(taxes.value))
+    n = int(np.prod(shape)) if shape else 1
+    return top[:n].reshape(shape).copy(), bdiffs, pdiffs
