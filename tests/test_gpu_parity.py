@@ -161,6 +161,31 @@ def test_euclid_speculation_miss_falls_back_exactly(D, oracle, hiplib):
     assert_bitexact(host(out["s_neg"]).ravel(), sn.ravel(), "triplet s_neg")
 
 
+@pytest.mark.parametrize("D", [300, 200, 52])
+def test_euclid_non_finite_inputs(D, oracle, hiplib):
+    """Inf / NaN / huge coordinates: the speculative stitch must not turn them into something else
+    (a window miss falls back to the sequential walk).  Compared with the oracle; NaNs match NaNs."""
+    from mms_answer_selection_amd import capi
+    N = 8
+    r = rng(D)
+    q, a = qa(r, N, 1, 1, D)
+    q[0, 0, 5] = np.inf                       # dist = inf -> T = 0
+    q[1, 0, D - 1] = np.nan                   # dist = NaN -> T = NaN
+    q[2, 0, :] = 3e19                         # squares overflow to inf half-way through
+    a[3, 0, 7] = -np.inf
+    q[4, 0, 0] = 1e19
+    a[4, 0, 0] = -1e19                        # a single huge square, finite sum
+    dT = r.standard_normal((N, 1, 1, 1)).astype(np.float32)
+    with np.errstate(all="ignore"):
+        top_ref, _, _ = oracle.simcross_forward(1, q, a)
+        dq_ref, da_ref, _, _ = oracle.simcross_backward(1, q, a, top_ref, dT)
+    top, gq, ga = nan_like(top_ref.shape), nan_like(q.shape), nan_like(a.shape)
+    capi.simcross_forward_backward(1, dev(q), dev(a), dev(dT), top, gq, ga)
+    assert_bitexact(host(top), top_ref, "top")
+    assert_bitexact(host(gq), dq_ref, "dq")
+    assert_bitexact(host(ga), da_ref, "da")
+
+
 def test_euclid_subnormal_squares(oracle, hiplib):
     """Squares in the fp32 subnormal range: the packed adds of the chain must not flush."""
     from mms_answer_selection_amd import capi
