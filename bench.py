@@ -234,19 +234,53 @@ def run(args):
         if world > 1:
             gather_bucket(gi % 2)
 
+    tails = {}
+
+    def tail_graph(gi, rem):
+        """A hipGraph of the first `rem` steps of group gi (a --steps / --warmup that is not a
+        multiple of GROUP must not fall back to host-paced launches inside the timed region)."""
+        key = (gi % period, rem)
+        if use_graph and key not in tails:
+            b = buckets[gi % 2]
+            cap2 = torch.cuda.Stream()
+            cap2.wait_stream(main)
+            with torch.cuda.stream(cap2):
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph, stream=cap2):
+                    for s in range(rem):
+                        step(0 if args.warm else (gi % ngroups) * G + s, b[s])
+            main.wait_stream(cap2)
+            tails[key] = gph
+        return tails.get(key)
+
     def run_steps(k, g0):
         full, rem = divmod(k, G)
         for i in range(full):
             run_group(g0 + i)
         if rem:                                        # time EXACTLY k steps
-            b = buckets[(g0 + full) % 2]
+            gi = g0 + full
+            b = buckets[gi % 2]
             if world > 1:
-                main.wait_event(bucket_free[(g0 + full) % 2])
-            for s in range(rem):
-                step(0 if args.warm else ((g0 + full) % ngroups) * G + s, b[s])
+                main.wait_event(bucket_free[gi % 2])
+            gph = tail_graph(gi, rem)
+            if gph is not None:
+                gph.replay()
+            else:
+                for s in range(rem):
+                    step(0 if args.warm else (gi % ngroups) * G + s, b[s])
             if world > 1:
-                gather_bucket((g0 + full) % 2)
+                gather_bucket(gi % 2)
         return g0 + full + (1 if rem else 0)
+
+    # capture the partial groups this run will need BEFORE anything is timed
+    _fw, _rw = divmod(args.warmup, G)
+    if _rw:
+        tail_graph(_fw, _rw)
+    _g_after_warm = _fw + (1 if _rw else 0)
+    _fs, _rs = divmod(args.steps, G)
+    if _rs:
+        tail_graph(_g_after_warm + _fs, _rs)
+    torch.cuda.synchronize()
 
     def fence():
         torch.cuda.synchronize()
