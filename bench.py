@@ -488,6 +488,29 @@ def other_configs(torch, capi):
         "us_per_step": us, "pairs_per_s": N / (us * 1e-6),
         "frac_hbm_unfused_bytes": b_unfused / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": "hbm",
         "dtype": "f16 storage / f32 arithmetic"}
+    del qh, ah, dT, top, dqh, dah
+    # cfg 4: scoring only -- the TREC-QA test split (1517 candidates, 40 x 40 word grids, Dw = 50),
+    # whole and as the 190-candidate shard one of 8 GPUs scores, plus MAP + MRR on 1517 sentence scores
+    for name, n in (("cfg4_scoring_1517x40x40x50_forward", 1517), ("cfg4_shard_190x40x40x50_forward", 190)):
+        qg, ag = rnd(n, 40, 50), rnd(n, 40, 50)
+        tg = torch.empty(n, 1, 40, 40, device="cuda")
+        us = _graph_time(torch, lambda: capi.simcross_forward(1, qg, ag, tg))
+        b = 4.0 * (2 * n * 40 * 50 + n * 1600)                       # SURVEY 8(d) B_fwd
+        out[name] = {"us_per_step": us, "pairs_per_s": n / (us * 1e-6), "GBps_algorithmic": b / us / 1e3,
+                     "bound": "fp32 VALU (3 flop per (j,k,d), d-ordered sums)"}
+        del qg, ag, tg
+    n = 1517
+    sc = torch.rand(n, device="cuda", generator=g)
+    prob = torch.stack([1 - sc, sc], 1).contiguous()
+    lab = (torch.rand(n, device="cuda", generator=g) < 0.2).float()
+    grp = torch.sort(torch.randint(0, 68, (n,), device="cuda", generator=g).float()).values
+    capi.rank_map_mrr(prob, lab, grp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        capi.rank_map_mrr(prob, lab, grp)
+    out["cfg4_map_mrr_1517_candidates"] = {"us_per_call": (time.perf_counter() - t0) / 20 * 1e6,
+                                            "note": "sort + walks + folds + device-to-host copy of the three scalars"}
     torch.cuda.empty_cache()
     return out
 
