@@ -835,11 +835,21 @@ __global__ __launch_bounds__(256) void cross_bwd_tiled_kernel(
   const float* Tn = top + (size_t)n * JK;
   const float* gn = top_diff + (size_t)n * JK;
 
-  for (int e = threadIdx.x; e < JK; e += 256) {
-    if (MODE == 1) {
-      const EuclidCoef k = euclid_coef(Tn[e], gn[e]);
+  for (int e0 = threadIdx.x; MODE == 1 && e0 < JK; e0 += 256 * 8) {
+    float tv[8], gv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int e = min(e0 + 256 * u, JK - 1); tv[u] = Tn[e]; gv[u] = gn[e]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u;
+      if (e >= JK) break;
+      const EuclidCoef k = euclid_coef(tv[u], gv[u]);
       t_c[e] = k.c;
       if (EXACT) { t_den[e] = k.den; t_rcp[e] = k.rcp; } else { t_r[e] = (float)k.rcp; }
+    }
+  }
+  for (int e = threadIdx.x; MODE != 1 && e < JK; e += 256) {
+    if (MODE == 1) {
     } else {
       const int j = e / W2, kk = e - j * W2;
       const float n0 = norm0[(size_t)n * W1 + j], n1 = norm1[(size_t)n * W2 + kk];
@@ -849,14 +859,25 @@ __global__ __launch_bounds__(256) void cross_bwd_tiled_kernel(
       t_b2[e] = Tn[e] / (n1 * n1);
     }
   }
-  for (int e = threadIdx.x; e < W1 * kBwdDC; e += 256) {
-    const int j = e >> 5, dd = e & 31;
-    qs[j * LS + dd] = dd < dn ? qn[(size_t)j * D + d0 + dd] : 0.f;
-  }
-  for (int e = threadIdx.x; e < W2 * kBwdDC; e += 256) {
-    const int k = e >> 5, dd = e & 31;
-    as[k * LS + dd] = dd < dn ? an[(size_t)k * D + d0 + dd] : 0.f;
-  }
+  // eight unconditional (clamped) loads per thread in flight before the first LDS write; a rolled
+  // `ok ? load : 0` loop paid one memory round trip per iteration
+  auto stage = [&](const float* src, float* dst, int W) {
+    for (int base = 0; base < W * kBwdDC; base += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = base + threadIdx.x + 256 * u;
+        v[u] = src[(size_t)min(e >> 5, W - 1) * D + min(d0 + (e & 31), D - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = base + threadIdx.x + 256 * u;
+        if (e < W * kBwdDC) dst[(e >> 5) * LS + (e & 31)] = (e & 31) < dn ? v[u] : 0.f;
+      }
+    }
+  };
+  stage(qn, qs, W1);
+  stage(an, as, W2);
   __syncthreads();
 
   float* dqn = dq + (size_t)n * W1 * D;
