@@ -882,6 +882,42 @@ __global__ __launch_bounds__(256) void cross_bwd_tiled_kernel(
 
   float* dqn = dq + (size_t)n * W1 * D;
   float* dan = da + (size_t)n * W2 * D;
+  if (MODE == 1 && !EXACT) {
+    // fp32 arithmetic: a thread owns FOUR consecutive d of one row, so the per-(j,k) coefficients
+    // c and fl32(1/den) are read from LDS once per four terms (6 LDS reads per 4 terms instead of
+    // 12: this loop is LDS-bandwidth-bound); every sum still runs over k (or j) ascending.
+    for (int e = threadIdx.x; do_dq && e < W1 * (kBwdDC / 4); e += 256) {
+      const int j = e >> 3, dd0 = (e & 7) * 4;
+      if (dd0 >= dn) continue;
+      float qv[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) qv[u] = qs[j * LS + dd0 + u];
+      for (int k = 0; k < W2; ++k) {
+        const float c = t_c[j * W2 + k], r = t_r[j * W2 + k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += (c * (qv[u] - as[k * LS + dd0 + u])) * r;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (dd0 + u < dn) dqn[(size_t)j * D + d0 + dd0 + u] = acc[u];
+    }
+    for (int e = threadIdx.x; do_da && e < W2 * (kBwdDC / 4); e += 256) {
+      const int k = e >> 3, dd0 = (e & 7) * 4;
+      if (dd0 >= dn) continue;
+      float av[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) av[u] = as[k * LS + dd0 + u];
+      for (int j = 0; j < W1; ++j) {
+        const float c = t_c[j * W2 + k], r = t_r[j * W2 + k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += -((c * (qs[j * LS + dd0 + u] - av[u])) * r);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (dd0 + u < dn) dan[(size_t)k * D + d0 + dd0 + u] = acc[u];
+    }
+    return;
+  }
   for (int e = threadIdx.x; do_dq && e < W1 * kBwdDC; e += 256) {
     const int j = e >> 5, dd = e & 31;
     if (dd >= dn) continue;
