@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
 
   // staging registers: A tile 128x16 -> 8 per thread, B tile 16x64 -> 4 per thread
   float ra[8], rb[4];
+  bool oka[8], okb[4];
   auto load_tiles = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
@@ -73,7 +74,10 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
       if (g.a_ifast) { i = t & 127; k = (t >> 7) + 2 * p; }
       else { k = t & 15; i = (t >> 4) + 16 * p; }
       const int gi = i0 + i, gk = k0 + k;
-      ra[p] = (gi < g.M && gk < kend) ? A[gi * g.a_rs + gk * g.a_cs] : 0.f;
+      // clamped, unconditional load; zeroed at the LDS store (as `ok ? load : 0` the loads are
+      // emitted one by one, each waited for: see the fast kernel below)
+      oka[p] = gi < g.M && gk < kend;
+      ra[p] = A[(long long)min(gi, g.M - 1) * g.a_rs + (long long)min(gk, g.K - 1) * g.a_cs];
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -81,7 +85,8 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
       if (g.b_jfast) { j = t & 63; k = (t >> 6) + 4 * p; }
       else { k = t & 15; j = (t >> 4) + 16 * p; }
       const int gj = j0 + j, gk = k0 + k;
-      rb[p] = (gj < g.N && gk < kend) ? B[gk * g.b_rs + gj * g.b_cs] : 0.f;
+      okb[p] = gj < g.N && gk < kend;
+      rb[p] = B[(long long)min(gk, g.K - 1) * g.b_rs + (long long)min(gj, g.N - 1) * g.b_cs];
     }
   };
   auto store_tiles = [&]() {
@@ -90,14 +95,14 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
       int i, k;
       if (g.a_ifast) { i = t & 127; k = (t >> 7) + 2 * p; }
       else { k = t & 15; i = (t >> 4) + 16 * p; }
-      As[k * LSA + i] = ra[p];
+      As[k * LSA + i] = oka[p] ? ra[p] : 0.f;
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       int j, k;
       if (g.b_jfast) { j = t & 63; k = (t >> 6) + 4 * p; }
       else { k = t & 15; j = (t >> 4) + 16 * p; }
-      Bs[k * LSB + j] = rb[p];
+      Bs[k * LSB + j] = okb[p] ? rb[p] : 0.f;
     }
   };
 
