@@ -157,6 +157,21 @@ int mms_simmatrix_backward_f32(int N, int K1, int K2, const float* q,
                                float* dq, float* da, float* dW, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* Same call for a caller that kept the forward's product: qw (N,K2) is what
+ * mms_simmatrix_forward_f32 wrote to qw_scratch for the SAME q and W, unchanged
+ * since.  da_j = dT_j * (W^T q_j) (:88) is row j of that product times dT_j, so
+ * the call scales it instead of recomputing it -- same bits as the call above,
+ * one GEMM fewer.  qw may be the da buffer itself (in place), which is where the
+ * reference's forward leaves it (bottom[1]'s diff, :58). */
+int mms_simmatrix_backward_cached_f32(int N, int K1, int K2, const float* q,
+                                      const float* a, const float* W,
+                                      const float* qw, const float* top_diff,
+                                      int param_propagate_down,
+                                      int propagate_down0, int propagate_down1,
+                                      float* dq, float* da, float* dW,
+                                      void* workspace, size_t workspace_bytes,
+                                      void* stream);
+
 size_t mms_simmatrix_workspace_bytes(int N, int K1, int K2);
 
 /* ------------------------------------------------------------------------- *

@@ -27,6 +27,7 @@ _SIGNATURES = {
     "mms_simmatrix_workspace_bytes": (_sz, [_i] * 3),
     "mms_simmatrix_forward_f32": (_i, [_i] * 3 + [_vp] * 6),
     "mms_simmatrix_backward_f32": (_i, [_i] * 3 + [_vp] * 4 + [_i] * 3 + [_vp] * 4 + [_sz, _vp]),
+    "mms_simmatrix_backward_cached_f32": (_i, [_i] * 3 + [_vp] * 5 + [_i] * 3 + [_vp] * 4 + [_sz, _vp]),
     "mms_pairrank_workspace_bytes": (_sz, [_i]),
     "mms_pairrank_forward_f32": (_i, [_i, _f] + [_vp] * 7 + [_sz, _vp]),
     "mms_pairrank_backward_f32": (_i, [_i, _f] + [_vp] * 3 + [_i, _i] + [_vp] * 3),
@@ -170,10 +171,18 @@ def simmatrix_forward(q, a, W, top, qw_scratch):
 
 
 def simmatrix_backward(q, a, W, top_diff, dq, da, dW, param_propagate_down=True,
-                       propagate_down=(True, True), ws=None):
+                       propagate_down=(True, True), ws=None, qw=None):
+    """qw: the forward's qw_scratch (same q, W; may be `da` itself) -> the cached entry point."""
     N = q.shape[0]
     K1, K2 = W.shape
     wsp, wsb = (ws or _default_ws).get(lib().mms_simmatrix_workspace_bytes(N, K1, K2), q.device)
+    if qw is not None:
+        check(lib().mms_simmatrix_backward_cached_f32(
+            N, K1, K2, _ptr(q, "q"), _ptr(a, "a"), _ptr(W, "W"), _ptr(qw, "qw"), _ptr(top_diff, "top_diff"),
+            int(bool(param_propagate_down)), int(bool(propagate_down[0])), int(bool(propagate_down[1])),
+            _ptr(dq, "dq", True), _ptr(da, "da", True), _ptr(dW, "dW", True), wsp, wsb, _stream()),
+            "mms_simmatrix_backward_cached_f32")
+        return
     check(lib().mms_simmatrix_backward_f32(
         N, K1, K2, _ptr(q, "q"), _ptr(a, "a"), _ptr(W, "W"), _ptr(top_diff, "top_diff"),
         int(bool(param_propagate_down)), int(bool(propagate_down[0])), int(bool(propagate_down[1])),

@@ -24,6 +24,32 @@
 
 namespace mms {
 
+// Dev-only phase stamps (tools/gemmstamp.hip builds this file with -DMMS_GEMM_STAMPS): thread 0 of
+// every workgroup of the fast kernel records s_memtime at its phase boundaries, plus where it ran.
+#ifdef MMS_GEMM_STAMPS
+__device__ unsigned long long* mms_gemm_stamp_buf = nullptr;
+#define MMS_GSTAMP(k)                                                                          \
+  do {                                                                                         \
+    if (mms_gemm_stamp_buf && threadIdx.x == 0)                                                \
+      mms_gemm_stamp_buf[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define MMS_GSTAMP_REAL(k)                                                                     \
+  do {                                                                                         \
+    if (mms_gemm_stamp_buf && threadIdx.x == 0)                                                \
+      mms_gemm_stamp_buf[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#define MMS_GSTAMP_WHERE()                                                                     \
+  do {                                                                                         \
+    if (mms_gemm_stamp_buf && threadIdx.x == 0)                                                \
+      mms_gemm_stamp_buf[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + 7] = \
+          ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); \
+  } while (0)
+#else
+#define MMS_GSTAMP(k) do {} while (0)
+#define MMS_GSTAMP_WHERE() do {} while (0)
+#define MMS_GSTAMP_REAL(k) do {} while (0)
+#endif
+
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 struct GemmArgs {
@@ -181,7 +207,26 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
   constexpr int FH = FK / 2;       // k values per half-wave per tile
   __shared__ float As2[2][FM * LSK];            // double-buffered: one barrier per k-tile
   __shared__ float Bs2[2][FK * LSJ];
-  const int z = blockIdx.z;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own
+  // L2) in linear-id order (x fastest, then y, then z), so linear ids that differ by 8 share an L2.
+  // Remap so that CONSECUTIVE logical tiles land on one XCD: the column tiles of one row panel
+  // (they re-read the same A rows), and -- for a split-K product -- all tiles of one k-chunk (each
+  // re-reads the chunk's A and B slabs; dealt over 8 L2s those slabs came from HBM 6 times over).
+  MMS_GSTAMP(0);
+  MMS_GSTAMP_REAL(4);
+  MMS_GSTAMP_WHERE();
+  int bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
+  {
+    const int plane = gridDim.x * gridDim.y, total = plane * gridDim.z;
+    if ((total & 7) == 0) {
+      const int id = z * plane + by * gridDim.x + bx;
+      int tl = (id & 7) * (total >> 3) + (id >> 3);
+      z = tl / plane;
+      tl -= z * plane;
+      by = tl / gridDim.x;
+      bx = tl - by * gridDim.x;
+    }
+  }
   const int ks = z % g.ksplit;
   const int b1 = (z / g.ksplit) % g.nb1;
   const int b0 = (z / g.ksplit) / g.nb1;
@@ -190,19 +235,6 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
   float* C = g.C + b0 * g.c_b0 + b1 * g.c_b1 + ks * g.c_ks;
   const int kbeg = ks * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own
-  // L2), so linear ids that differ by 8 share an L2.  Remap so that CONSECUTIVE tiles -- the
-  // column tiles of one row panel, which re-read the same A rows -- land on one XCD.
-  int bx = blockIdx.x, by = blockIdx.y;
-  {
-    const int total = gridDim.x * gridDim.y;
-    if ((total & 7) == 0) {
-      const int id = by * gridDim.x + bx;
-      const int tl = (id & 7) * (total >> 3) + (id >> 3);
-      by = tl / gridDim.x;
-      bx = tl - by * gridDim.x;
-    }
-  }
   const int i0 = by * FM, j0 = bx * FN;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
@@ -284,6 +316,7 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
     load(kbeg);
     store(0);
     __syncthreads();
+    MMS_GSTAMP(1);
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += FK, cur ^= 1) {
       const bool more = k0 + FK < kend;
@@ -306,6 +339,7 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
     }
   }
 
+  MMS_GSTAMP(2);
   const float* rs = g.rowscale ? g.rowscale + b0 * g.rs_b0 : nullptr;
   const float* ad = g.addend ? g.addend + b1 * g.ad_b1 : nullptr;
   const int gj = j0 + wn * 32 + r;
@@ -321,6 +355,11 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
     else if (g.stream_c) __builtin_nontemporal_store(v, c);
     else *c = v;
   }
+#ifdef MMS_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MMS_GSTAMP(3);
+  MMS_GSTAMP_REAL(5);
 }
 
 static bool mult4(long long x) { return (x & 3) == 0; }
@@ -423,6 +462,28 @@ __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__
     out[e] = scale[e / cols] * x[e];
 }
 
+// out[r][c] = scale[r] * x[r][c]; out may BE x.
+__global__ __launch_bounds__(256) void rowscale_inplace_ok_kernel(const float* x, const float* __restrict__ scale,
+                                                                  float* out, long long rows, int cols) {
+  const long long n = rows * cols;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride)
+    out[e] = scale[e / cols] * x[e];
+}
+
+// out[r][c] = scale[r] * x[r][c] for 16-byte-aligned rows (cols % 4 == 0); out may BE x (each thread
+// reads the float4 it overwrites).  Streaming stores: the result is read next by another layer.
+__global__ __launch_bounds__(256) void rowscale4_kernel(const float4* x, const float* __restrict__ scale,
+                                                        float4* out, long long rows, int cols4) {
+  const long long n = rows * cols4;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
+    const float sc = scale[e / cols4];
+    const float4 v = x[e];
+    stream_store(out + e, make_float4(sc * v.x, sc * v.y, sc * v.z, sc * v.w));
+  }
+}
+
 // top[r] = dot(x[r], y[r]) (+ bias)  -- one wave per row, fixed butterfly.
 // top index = r*top_stride ; bias is a single value (may be null).
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x,
@@ -466,6 +527,10 @@ static int pick_ksplit(int Mt, int Nt, int K, int* kchunk) {
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   if (want > 256) want = 256;
+  if (want >= 8) {                              // tiles x splits divisible by 8: the XCD-aware order applies
+    const long long w8 = (want + 7) / 8 * 8;
+    want = w8 <= maxs ? w8 : (maxs >= 8 ? maxs / 8 * 8 : want);
+  }
   int chunk = (int)((K + want - 1) / want);
   chunk = (chunk + 31) / 32 * 32;               // a multiple of either k-tile depth (16, 32)
   *kchunk = chunk;
@@ -609,9 +674,12 @@ int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, con
   return launch_status();
 }
 
+// qw (optional): the forward's Q.W, unchanged since; may alias da.  da_j = dT_j * (W^T q_j) is row j of
+// Q.W scaled by dT_j -- the product the forward already made with the same kernel and k order, so
+// reusing it returns the same bits as recomputing it and saves one of the four GEMMs of a step.
 int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, const float* W,
                        const float* top_diff, int ppd, int pd0, int pd1, float* dq, float* da,
-                       float* dW, void* ws, size_t ws_bytes, hipStream_t s) {
+                       float* dW, const float* qw, void* ws, size_t ws_bytes, hipStream_t s) {
   const SimMatrixWs lay = simmatrix_ws(N, K1, K2);
   if (ppd) {
     if (!ws || ws_bytes < lay.total) return MMS_ERR_WORKSPACE;
@@ -639,7 +707,17 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
     g.stream_c = 1;                             // read next by another layer, not by this call
     gemm_launch(g, 1, s);
   }
-  if (pd1) {
+  if (pd1 && qw) {
+    if ((K2 & 3) == 0 && aligned16(qw) && aligned16(da)) {
+      hipLaunchKernelGGL(rowscale4_kernel, dim3(ew_blocks((long long)N * (K2 / 4))), dim3(256), 0, s,
+                         reinterpret_cast<const float4*>(qw), top_diff, reinterpret_cast<float4*>(da),
+                         (long long)N, K2 / 4);
+    } else {
+      const float* x = qw;
+      hipLaunchKernelGGL(rowscale_inplace_ok_kernel, dim3(ew_blocks((long long)N * K2)), dim3(256), 0, s, x,
+                         top_diff, da, (long long)N, K2);
+    }
+  } else if (pd1) {
     // da_j = dT_j * (W^T q_j)   (:88, Trans, beta 0)
     GemmArgs g = gemm_args(N, K2, K1, q, K1, 1, W, K2, 1, da, K2);
     g.rowscale = top_diff;

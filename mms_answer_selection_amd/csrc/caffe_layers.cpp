@@ -120,6 +120,14 @@ inline int simmatrix_forward(int N, int K1, int K2, const float* q, const float*
 inline int simmatrix_forward(int N, int K1, int K2, const double* q, const double* a, const double* W, double* top, double* scr) {
   return mms_simmatrix_forward_f64(N, K1, K2, q, a, W, top, scr, nullptr);
 }
+inline int simmatrix_backward_cached(int N, int K1, int K2, const float* q, const float* a, const float* W, const float* qw,
+                                     const float* dT, int ppd, int pd0, int pd1, float* dq, float* da, float* dW, void* ws, size_t wsb) {
+  return mms_simmatrix_backward_cached_f32(N, K1, K2, q, a, W, qw, dT, ppd, pd0, pd1, dq, da, dW, ws, wsb, nullptr);
+}
+inline int simmatrix_backward_cached(int N, int K1, int K2, const double* q, const double* a, const double* W, const double*,
+                                     const double* dT, int ppd, int pd0, int pd1, double* dq, double* da, double* dW, void*, size_t) {
+  return mms_simmatrix_backward_f64(N, K1, K2, q, a, W, dT, ppd, pd0, pd1, dq, da, dW, nullptr);   // functional path: recomputes
+}
 inline int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, const float* W, const float* dT, int ppd,
                               int pd0, int pd1, float* dq, float* da, float* dW, void* ws, size_t wsb) {
   return mms_simmatrix_backward_f32(N, K1, K2, q, a, W, dT, ppd, pd0, pd1, dq, da, dW, ws, wsb, nullptr);
@@ -279,23 +287,42 @@ class SimMatrixLayer : public Layer<Dtype> {
     top[0]->Reshape(vector<int>{bottom[0]->shape(0), 1});
     const size_t ws = abi::simmatrix_ws(Dtype(0), M_, K1_, K2_);
     workspace_.Reshape(vector<int>{(int)((ws + sizeof(Dtype) - 1) / sizeof(Dtype))});
+    if (qw_.count() != M_ * K2_) qw_valid_ = false;
+    qw_.Reshape(vector<int>{M_, K2_});
   }
 
  protected:
   void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
   void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
 
-  // replaces sim_matrix_layer.cpp:53-65; Q*W lands in bottom[1]'s diff, as in the reference (:58)
+  // replaces sim_matrix_layer.cpp:53-65.  The reference parks Q*W in bottom[1]'s diff (:58) and
+  // recomputes W^T q_j per pair in Backward (:88); here the product is kept in a member blob --
+  // like SimCross's cached norms (sim_cross_layer.hpp:40-41) -- so that Backward scales it into
+  // bottom[1]'s diff instead of running the same GEMM again, whatever a caller did to that diff
+  // in between.
   void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
     mms_check(abi::simmatrix_forward(M_, K1_, K2_, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
                                      this->blobs_[0]->gpu_data(), top[0]->mutable_gpu_data(),
-                                     bottom[1]->mutable_gpu_diff()),
+                                     qw_.mutable_gpu_data()),
               "mms_simmatrix_forward");
+    qw_valid_ = true;
   }
   // replaces sim_matrix_layer.cpp:68-95
   void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down,
                     const vector<Blob<Dtype>*>& bottom) override {
     const bool ppd = this->param_propagate_down_[0];
+    if (qw_valid_) {
+      mms_check(abi::simmatrix_backward_cached(
+                    M_, K1_, K2_, bottom[0]->gpu_data(), bottom[1]->gpu_data(), this->blobs_[0]->gpu_data(),
+                    qw_.gpu_data(), top[0]->gpu_diff(), ppd, propagate_down[0], propagate_down[1],
+                    propagate_down[0] ? bottom[0]->mutable_gpu_diff() : nullptr,
+                    propagate_down[1] ? bottom[1]->mutable_gpu_diff() : nullptr,
+                    ppd ? this->blobs_[0]->mutable_gpu_diff() : nullptr,
+                    workspace_.count() ? workspace_.mutable_gpu_data() : nullptr,
+                    (size_t)workspace_.count() * sizeof(Dtype)),
+                "mms_simmatrix_backward_cached");
+      return;
+    }
     mms_check(abi::simmatrix_backward(
                   M_, K1_, K2_, bottom[0]->gpu_data(), bottom[1]->gpu_data(), this->blobs_[0]->gpu_data(),
                   top[0]->gpu_diff(), ppd, propagate_down[0], propagate_down[1],
@@ -308,6 +335,8 @@ class SimMatrixLayer : public Layer<Dtype> {
   }
   int K1_ = 0, K2_ = 0, M_ = 0;
   Blob<Dtype> workspace_;
+  Blob<Dtype> qw_;             // Q*W of the last Forward (M_, K2_)
+  bool qw_valid_ = false;
 };
 INSTANTIATE_CLASS_FD(SimMatrixLayer);
 REGISTER_LAYER_CLASS_FD(SimMatrix);

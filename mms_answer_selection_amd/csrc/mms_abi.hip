@@ -30,7 +30,7 @@ int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, con
                       float* top, float* qw, hipStream_t s);
 int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, const float* W,
                        const float* top_diff, int ppd, int pd0, int pd1, float* dq, float* da,
-                       float* dW, void* ws, size_t ws_bytes, hipStream_t s);
+                       float* dW, const float* qw, void* ws, size_t ws_bytes, hipStream_t s);
 // pairrank.hip
 size_t pairrank_workspace_bytes(int count);
 int pairrank_forward(int count, float margin, const float* a, const float* b, const float* y,
@@ -227,7 +227,22 @@ int mms_simmatrix_backward_f32(int N, int K1, int K2, const float* q, const floa
   if ((param_propagate_down && !dW) || (propagate_down0 && !dq) || (propagate_down1 && !da))
     return MMS_ERR_INVALID_ARG;
   return simmatrix_backward(N, K1, K2, q, a, W, top_diff, param_propagate_down, propagate_down0,
-                            propagate_down1, dq, da, dW, workspace, workspace_bytes,
+                            propagate_down1, dq, da, dW, nullptr, workspace, workspace_bytes,
+                            as_stream(stream));
+}
+
+int mms_simmatrix_backward_cached_f32(int N, int K1, int K2, const float* q, const float* a,
+                                      const float* W, const float* qw, const float* top_diff,
+                                      int param_propagate_down, int propagate_down0,
+                                      int propagate_down1, float* dq, float* da, float* dW,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (N < 0 || K1 <= 0 || K2 <= 0) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q || !a || !W || !qw || !top_diff) return MMS_ERR_INVALID_ARG;
+  if ((param_propagate_down && !dW) || (propagate_down0 && !dq) || (propagate_down1 && !da))
+    return MMS_ERR_INVALID_ARG;
+  return simmatrix_backward(N, K1, K2, q, a, W, top_diff, param_propagate_down, propagate_down0,
+                            propagate_down1, dq, da, dW, qw, workspace, workspace_bytes,
                             as_stream(stream));
 }
 

@@ -379,6 +379,17 @@ def test_simmatrix(shape, oracle, hiplib):
     assert_bitexact(host(gW2), dW0, "dW untouched")
     assert_bitexact(host(ga2), host(ga), "da")
 
+    # cached entry point: the forward's Q*W is scaled instead of recomputed -- same bits, also in place
+    gq3, ga3, gW3 = nan_like((N, K1)), nan_like((N, K2)), dev(dW0)
+    capi.simmatrix_backward(qd, ad, Wd, dTd, gq3, ga3, gW3, qw=scratch)
+    assert_bitexact(host(gq3), host(gq), "dq (cached call)")
+    assert_bitexact(host(ga3), host(ga), "da from the cached Q*W")
+    assert_bitexact(host(gW3), host(gW), "dW (cached call)")
+    inplace = scratch.clone()                         # the reference's layout: Q*W sits in bottom[1].diff
+    capi.simmatrix_backward(qd, ad, Wd, dTd, None, inplace, None, param_propagate_down=False,
+                            propagate_down=(False, True), qw=inplace)
+    assert_bitexact(host(inplace), host(ga), "da scaled in place")
+
 
 # --------------------------------------------------------------------------- #
 # PairRankLoss

@@ -125,13 +125,17 @@ def test_simmatrix_layer_quirks(L, oracle):
     lay.SetUp([bq, ba], [top])
     W = lay.blobs[0].data.copy()
     assert W.shape == (K1, K2) and W.min() >= -0.08 and W.max() <= 0.08 and W.std() > 0.03
+    ba.diff[...] = 7.0
     lay.Forward([bq, ba], [top])
     assert top.shape == (N, 1)
     top_ref, scratch_ref = oracle.simmatrix_forward(q, a, W)
     assert_close(top.data, top_ref, TOL)
-    assert_close(ba.diff, scratch_ref, TOL)          # forward scribbles on bottom[1].diff (:58)
+    # flagged difference: the reference's forward scribbles Q*W on bottom[1].diff (:58); this layer
+    # keeps the product in a member blob for Backward and leaves the bottom's diff alone
+    assert (ba.diff == 7.0).all()
     dT = r.standard_normal((N, 1)).astype(np.float32)
     top.diff[...] = dT
+    ba.diff[...] = np.nan                            # whatever happens to that diff before Backward
     lay.blobs[0].diff[...] = 1.5                      # accumulates (:73-80)
     lay.Backward([top], [True, True], [bq, ba])
     dq_ref, da_ref, dW_ref = oracle.simmatrix_backward(q, a, W, dT, dW_in=np.full_like(W, 1.5))

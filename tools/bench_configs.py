@@ -69,10 +69,11 @@ def simmatrix(N, K1, K2, iters=20):
     dT = rnd(N, 1, scale=1.0)
     dq, da, dW = torch.empty_like(q), torch.empty_like(a), torch.zeros_like(W)
     tf = timeit(lambda: capi.simmatrix_forward(q, a, W, top, scr), iters)
-    tb = timeit(lambda: capi.simmatrix_backward(q, a, W, dT, dq, da, dW), iters)
+    tb = timeit(lambda: capi.simmatrix_backward(q, a, W, dT, dq, da, dW, qw=scr), iters)   # the Layer's sequence
+    tb_re = timeit(lambda: capi.simmatrix_backward(q, a, W, dT, dq, da, dW), iters)
     ff = 2.0 * N * K1 * K2 + 2.0 * N * K2
     fb = 6.0 * N * K1 * K2
-    print(json.dumps({"op": "SimMatrix", "N": N, "K1": K1, "K2": K2, "fwd_us": tf, "bwd_us": tb,
+    print(json.dumps({"op": "SimMatrix", "N": N, "K1": K1, "K2": K2, "fwd_us": tf, "bwd_us": tb, "bwd_recomputing_us": tb_re,
                       "fwd_TFLOPs": ff / tf / 1e6, "bwd_TFLOPs": fb / tb / 1e6,
                       "frac_mfma_fwd_bwd": (ff + fb) / ((tf + tb) * 1e-6) / 157.3e12,
                       "pairs_per_s_fwd_bwd": N / ((tf + tb) * 1e-6)}), flush=True)
