@@ -488,6 +488,24 @@ def other_configs(torch, capi):
         "us_per_step": us, "pairs_per_s": N / (us * 1e-6), "TFLOPs": flops / us / 1e6,
         "frac_mfma_fp32_peak": flops / (us * 1e-6) / 157.3e12, "bound": "mfma", "dtype": "f32"}
     del q, a, W, dT, top, scr, dq, da, dW
+    # cfg 1: the driver's training geometry, SimCross bilinear M = 4 with bias (do_trec_qa_clean.py:452-496)
+    for (N1, Wd, D1, M1) in ((32, 40, 300, 4), (50, 40, 50, 4)):
+        q1, a1 = rnd(N1, Wd, D1), rnd(N1, Wd, D1)
+        W1 = torch.rand(M1, D1, D1, device="cuda", generator=g) * 0.16 - 0.08
+        b1 = torch.zeros(M1, Wd, Wd, device="cuda")
+        t1 = torch.empty(N1, M1, Wd, Wd, device="cuda")
+        dT1 = torch.randn(N1, M1, Wd, Wd, device="cuda", generator=g)
+        dq1, da1, dW1, db1 = torch.empty_like(q1), torch.empty_like(a1), torch.empty_like(W1), torch.zeros_like(b1)
+
+        def cfg1():
+            capi.simcross_forward(2, q1, a1, t1, W=W1, bias=b1, ws=ws)
+            capi.simcross_backward(2, q1, a1, t1, dT1, dq1, da1, W=W1, bias_term=True, dW=dW1, dbias=db1, ws=ws)
+        us = _graph_time(torch, cfg1, iters=4)
+        fl = 2.0 * N1 * M1 * Wd * D1 * (D1 + Wd) + 8.0 * N1 * M1 * Wd * D1 * (D1 + Wd)
+        out["cfg1_bilinear_%dx%dx%dx%d_M%d_fwd_bwd" % (N1, Wd, Wd, D1, M1)] = {
+            "us_per_step": us, "pairs_per_s": N1 / (us * 1e-6), "TFLOPs": fl / us / 1e6,
+            "frac_mfma_fp32_peak": fl / (us * 1e-6) / 157.3e12, "bound": "mfma / launch", "dtype": "f32"}
+        del q1, a1, W1, b1, t1, dT1, dq1, da1, dW1, db1
     # cfg 5 shard: 8192 pairs x 1024-d, fp16 storage, fused fwd+bwd (one launch)
     N, D = 8192, 1024
     qh, ah = rnd(N, 1, D).half(), rnd(N, 1, D).half()

@@ -60,6 +60,9 @@ struct GemmArgs {
   // blockIdx.z = (b0 * nb1 + b1) * ksplit + ks
   int nb1, ksplit, kchunk;
   long long a_b0, a_b1, b_b0, b_b1, c_b0, c_b1, c_ks;
+  // "stacked" split-K: chunk ks is a product of its own, A + ks*a_ks times B + ks*b_ks over k in [0, K)
+  // (sum over measures of U_m W_m: K is not one contiguous axis); partials land at C + ks*c_ks as usual.
+  int ks_stacked; long long a_ks, b_ks;
   const float* rowscale; long long rs_b0;  // optional C(i,j) = rowscale[i] * acc
   const float* addend; long long ad_b1;    // optional C(i,j) += addend[i*ldc + j]
   const float* bkscale;                    // optional B(k,j) *= bkscale[k] on load (fast j-vector path)
@@ -85,8 +88,9 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
   const float* A = g.A + b0 * g.a_b0 + b1 * g.a_b1;
   const float* B = g.B + b0 * g.b_b0 + b1 * g.b_b1;
   float* C = g.C + b0 * g.c_b0 + b1 * g.c_b1 + ks * g.c_ks;
-  const int kbeg = ks * g.kchunk;
-  const int kend = min(g.K, kbeg + g.kchunk);
+  int kbeg = ks * g.kchunk;
+  int kend = min(g.K, kbeg + g.kchunk);
+  if (g.ks_stacked) { A += ks * g.a_ks; B += ks * g.b_ks; kbeg = 0; kend = g.K; }
   const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
 
@@ -200,11 +204,16 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
 // half as many boundaries for the driver's 32 x 40 x 40 x 300 bilinear products.
 constexpr int FM = 64, FN = 64, LSJ = FN + 4;
 
-template <bool A_KVEC, bool B_JVEC, bool KSCALE, int FK>
+// VW = floats per global load: 4 (16-byte-aligned rows, e.g. D = 300 / 1024) or 2 (8-byte-aligned rows:
+// the driver's default D = 50, whose rows are 200 bytes).
+template <bool A_KVEC, bool B_JVEC, bool KSCALE, int FK, int VW>
 __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
+  typedef float VT __attribute__((ext_vector_type(VW)));
   constexpr int LSK = FK + 4;
-  constexpr int FSL = FK / 16;     // float4 load slots per operand per thread per tile
-  constexpr int FH = FK / 2;       // k values per half-wave per tile
+  constexpr int FSL = FK / (4 * VW);   // vector load slots per operand per thread per tile
+  constexpr int KV = FK / VW;          // vectors along the k extent of a tile
+  constexpr int JV = 64 / VW;          // vectors along the 64-wide extent of a tile
+  constexpr int FH = FK / 2;           // k values per half-wave per tile
   __shared__ float As2[2][FM * LSK];            // double-buffered: one barrier per k-tile
   __shared__ float Bs2[2][FK * LSJ];
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own
@@ -233,8 +242,9 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
   const float* A = g.A + b0 * g.a_b0 + b1 * g.a_b1;
   const float* B = g.B + b0 * g.b_b0 + b1 * g.b_b1;
   float* C = g.C + b0 * g.c_b0 + b1 * g.c_b1 + ks * g.c_ks;
-  const int kbeg = ks * g.kchunk;
-  const int kend = min(g.K, kbeg + g.kchunk);
+  int kbeg = ks * g.kchunk;
+  int kend = min(g.K, kbeg + g.kchunk);
+  if (g.ks_stacked) { A += ks * g.a_ks; B += ks * g.b_ks; kbeg = 0; kend = g.K; }
   const int i0 = by * FM, j0 = bx * FN;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
@@ -244,23 +254,23 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
 #pragma unroll
   for (int sl = 0; sl < FSL; ++sl) {
     const int u = t + 256 * sl;
-    if (A_KVEC) { ai[sl] = u / (FK / 4); ak[sl] = (u % (FK / 4)) * 4; } else { ak[sl] = u >> 4; ai[sl] = (u & 15) * 4; }
-    if (B_JVEC) { bk[sl] = u >> 4; bj[sl] = (u & 15) * 4; } else { bj[sl] = u / (FK / 4); bk[sl] = (u % (FK / 4)) * 4; }
+    if (A_KVEC) { ai[sl] = u / KV; ak[sl] = (u % KV) * VW; } else { ak[sl] = u / JV; ai[sl] = (u % JV) * VW; }
+    if (B_JVEC) { bk[sl] = u / JV; bj[sl] = (u % JV) * VW; } else { bj[sl] = u / KV; bk[sl] = (u % KV) * VW; }
   }
   const float* pa[FSL];
   const float* pb[FSL];
   bool a_ok[FSL], b_ok[FSL];
 #pragma unroll
   for (int sl = 0; sl < FSL; ++sl) {
-    a_ok[sl] = i0 + ai[sl] < g.M;              // M % 4 == 0 on the i-vector path
-    b_ok[sl] = j0 + bj[sl] < g.N;              // N % 4 == 0 on the j-vector path
+    a_ok[sl] = i0 + ai[sl] < g.M;              // M % VW == 0 on the i-vector path
+    b_ok[sl] = j0 + bj[sl] < g.N;              // N % VW == 0 on the j-vector path
     pa[sl] = A + (long long)(i0 + ai[sl]) * g.a_rs + (long long)(kbeg + ak[sl]) * g.a_cs;
     pb[sl] = B + (long long)(kbeg + bk[sl]) * g.b_rs + (long long)(j0 + bj[sl]) * g.b_cs;
   }
   const long long a_step = (long long)FK * g.a_cs, b_step = (long long)FK * g.b_rs;
   const float* ksc = g.bkscale;
 
-  float4 ra[FSL], rb[FSL];
+  VT ra[FSL], rb[FSL];
   float sc[FSL];
   bool la[FSL], lb[FSL];                       // was the slot inside the matrix?
 #pragma unroll
@@ -274,8 +284,8 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
     for (int sl = 0; sl < FSL; ++sl) {
       la[sl] = a_ok[sl] && k0 + ak[sl] < kend;
       lb[sl] = b_ok[sl] && k0 + bk[sl] < kend;
-      ra[sl] = *reinterpret_cast<const float4*>(la[sl] ? pa[sl] : A);
-      rb[sl] = *reinterpret_cast<const float4*>(lb[sl] ? pb[sl] : B);
+      ra[sl] = *reinterpret_cast<const VT*>(la[sl] ? pa[sl] : A);
+      rb[sl] = *reinterpret_cast<const VT*>(lb[sl] ? pb[sl] : B);
       // the scale is only FETCHED here (clamped index, no dependent use): multiplying now
       // would put a vmcnt(0) wait in front of the MFMAs and drain the prefetch
       if (KSCALE) sc[sl] = ksc[min(k0 + bk[sl], g.K - 1)];
@@ -286,24 +296,24 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
   auto store = [&](int buf) {
     float* As = As2[buf];
     float* Bs = Bs2[buf];
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const VT zv = 0.f;
 #pragma unroll
     for (int sl = 0; sl < FSL; ++sl) {
-      if (!la[sl]) ra[sl] = z4;
-      if (!lb[sl]) rb[sl] = z4;
+      if (!la[sl]) ra[sl] = zv;
+      if (!lb[sl]) rb[sl] = zv;
       if (A_KVEC) {
-        *reinterpret_cast<float4*>(&As[ai[sl] * LSK + ak[sl]]) = ra[sl];
+        *reinterpret_cast<VT*>(&As[ai[sl] * LSK + ak[sl]]) = ra[sl];
       } else {
-        As[(ai[sl] + 0) * LSK + ak[sl]] = ra[sl].x; As[(ai[sl] + 1) * LSK + ak[sl]] = ra[sl].y;
-        As[(ai[sl] + 2) * LSK + ak[sl]] = ra[sl].z; As[(ai[sl] + 3) * LSK + ak[sl]] = ra[sl].w;
+#pragma unroll
+        for (int c = 0; c < VW; ++c) As[(ai[sl] + c) * LSK + ak[sl]] = ra[sl][c];
       }
       if (B_JVEC) {
-        float4 v = rb[sl];
-        if (KSCALE) { v.x *= sc[sl]; v.y *= sc[sl]; v.z *= sc[sl]; v.w *= sc[sl]; }
-        *reinterpret_cast<float4*>(&Bs[bk[sl] * LSJ + bj[sl]]) = v;
+        VT v = rb[sl];
+        if (KSCALE) v *= sc[sl];
+        *reinterpret_cast<VT*>(&Bs[bk[sl] * LSJ + bj[sl]]) = v;
       } else {
-        Bs[(bk[sl] + 0) * LSJ + bj[sl]] = rb[sl].x; Bs[(bk[sl] + 1) * LSJ + bj[sl]] = rb[sl].y;
-        Bs[(bk[sl] + 2) * LSJ + bj[sl]] = rb[sl].z; Bs[(bk[sl] + 3) * LSJ + bj[sl]] = rb[sl].w;
+#pragma unroll
+        for (int c = 0; c < VW; ++c) Bs[(bk[sl] + c) * LSJ + bj[sl]] = rb[sl][c];
       }
     }
   };
@@ -362,23 +372,30 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
   MMS_GSTAMP_REAL(5);
 }
 
-static bool mult4(long long x) { return (x & 3) == 0; }
-// which fast variant (if any) can run these arguments: 0 none, else 1 + 2*A_KVEC + B_JVEC
-static int gemm_fast_variant(const GemmArgs& g) {
-  if (g.kchunk % 32 != 0 && g.ksplit > 1) return 0;   // split boundaries must fall on k-tile boundaries (16 or 32)
+static bool multv(long long x, int vw) { return x % vw == 0; }
+// which fast variant (if any) can run these arguments: 0 none, else 1 + 2*A_KVEC + B_JVEC; *vw = floats
+// per global load (4, else 2)
+static int gemm_fast_variant(const GemmArgs& g, int* vw_out = nullptr) {
+  if (g.kchunk % 32 != 0 && g.ksplit > 1 && !g.ks_stacked) return 0;   // split boundaries must fall on k-tile boundaries (16 or 32)
   if (g.bkscale && !(g.b_cs == 1)) return 0;
-  const bool bases = aligned16(g.A) && aligned16(g.B) && mult4(g.a_b0) && mult4(g.a_b1) &&
-                     mult4(g.b_b0) && mult4(g.b_b1);
-  if (!bases || !mult4(g.K)) return 0;
-  int a_kvec;
-  if (g.a_cs == 1 && mult4(g.a_rs)) a_kvec = 1;
-  else if (g.a_rs == 1 && mult4(g.a_cs) && mult4(g.M)) a_kvec = 0;
-  else return 0;
-  int b_jvec;
-  if (g.b_cs == 1 && mult4(g.b_rs) && mult4(g.N)) b_jvec = 1;
-  else if (g.b_rs == 1 && mult4(g.b_cs)) b_jvec = 0;
-  else return 0;
-  return 1 + 2 * a_kvec + b_jvec;
+  for (int vw = 4; vw >= 2; vw -= 2) {
+    const uintptr_t am = (uintptr_t)(4 * vw - 1);
+    const bool bases = (reinterpret_cast<uintptr_t>(g.A) & am) == 0 && (reinterpret_cast<uintptr_t>(g.B) & am) == 0 &&
+                       multv(g.a_b0, vw) && multv(g.a_b1, vw) && multv(g.b_b0, vw) && multv(g.b_b1, vw) &&
+                       (!g.ks_stacked || (multv(g.a_ks, vw) && multv(g.b_ks, vw)));
+    if (!bases || !multv(g.K, vw)) continue;
+    int a_kvec;
+    if (g.a_cs == 1 && multv(g.a_rs, vw)) a_kvec = 1;
+    else if (g.a_rs == 1 && multv(g.a_cs, vw) && multv(g.M, vw)) a_kvec = 0;
+    else continue;
+    int b_jvec;
+    if (g.b_cs == 1 && multv(g.b_rs, vw) && multv(g.N, vw)) b_jvec = 1;
+    else if (g.b_rs == 1 && multv(g.b_cs, vw)) b_jvec = 0;
+    else continue;
+    if (vw_out) *vw_out = vw;
+    return 1 + 2 * a_kvec + b_jvec;
+  }
+  return 0;
 }
 
 static GemmArgs gemm_args(int M, int N, int K, const float* A, long long a_rs, long long a_cs,
@@ -406,15 +423,18 @@ static void gemm_launch(const GemmArgs& g0, int nb0, hipStream_t s) {
     g.B += (long long)b * g.b_b0;
     g.C += (long long)b * g.c_b0;
     if (g.rowscale) g.rowscale += (long long)b * g.rs_b0;
-    const int fv = gemm_fast_variant(g);
+    int vw = 4;
+    const int fv = gemm_fast_variant(g, &vw);
     if (fv) {
       dim3 grid((g.N + FN - 1) / FN, (g.M + FM - 1) / FM, nb * per_b0);
       const bool ksc = g.bkscale != nullptr;   // only with B_JVEC (gemm_fast_variant)
       const bool deep = (long long)grid.x * grid.y * grid.z <= 2 * 256;   // at most two workgroups per CU
 #define MMS_FAST(a, b, c)                                                                              \
   do {                                                                                                 \
-    if (deep) hipLaunchKernelGGL((gemm32_fast_kernel<a, b, c, 32>), grid, dim3(256), 0, s, g);         \
-    else hipLaunchKernelGGL((gemm32_fast_kernel<a, b, c, 16>), grid, dim3(256), 0, s, g);              \
+    if (deep && vw == 4) hipLaunchKernelGGL((gemm32_fast_kernel<a, b, c, 32, 4>), grid, dim3(256), 0, s, g);  \
+    else if (vw == 4) hipLaunchKernelGGL((gemm32_fast_kernel<a, b, c, 16, 4>), grid, dim3(256), 0, s, g);     \
+    else if (deep) hipLaunchKernelGGL((gemm32_fast_kernel<a, b, c, 32, 2>), grid, dim3(256), 0, s, g);        \
+    else hipLaunchKernelGGL((gemm32_fast_kernel<a, b, c, 16, 2>), grid, dim3(256), 0, s, g);                  \
   } while (0)
       switch (fv - 1) {
         case 0: MMS_FAST(false, false, false); break;
@@ -509,7 +529,15 @@ __global__ __launch_bounds__(256) void dbias_kernel(const float* __restrict__ to
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= per_n) return;
   float s = dbias[e];
-  for (int n = 0; n < N; ++n) s = top_diff[(size_t)n * per_n + e] + s;
+  int n = 0;
+  for (; n + 8 <= N; n += 8) {                 // 8 independent loads in flight, added in n order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = top_diff[(size_t)(n + u) * per_n + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s = v[u] + s;
+  }
+  for (; n < N; ++n) s = top_diff[(size_t)n * per_n + e] + s;
   dbias[e] = s;
 }
 
@@ -523,7 +551,7 @@ static unsigned ew_blocks(long long n) {
 static int pick_ksplit(int Mt, int Nt, int K, int* kchunk) {
   const long long tiles = (long long)((Mt + FM - 1) / FM) * ((Nt + FN - 1) / FN);
   long long want = (768 + tiles - 1) / tiles;   // aim for ~3 workgroups per CU
-  long long maxs = (K + 255) / 256;             // at least 256 of K per split
+  long long maxs = (K + 63) / 64;               // at least 64 of K (two deep k-tiles) per split
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   if (want > 256) want = 256;
@@ -539,7 +567,7 @@ static int pick_ksplit(int Mt, int Nt, int K, int* kchunk) {
 
 // ------------------------------ workspace layout ----------------------------
 struct BilinearWs {
-  size_t u_off, v_off, part_off, total;
+  size_t u_off, v_off, part_off, mpart_off, total;
   int ksplit, kchunk;
 };
 static BilinearWs bilinear_ws(int N, int W1, int W2, int D, int M) {
@@ -549,7 +577,9 @@ static BilinearWs bilinear_ws(int N, int W1, int W2, int D, int M) {
   w.u_off = 0;
   w.v_off = round_up(u * sizeof(float), 256);
   w.part_off = w.v_off + round_up(v * sizeof(float), 256);
-  w.total = w.part_off + round_up((size_t)w.ksplit * M * D * D * sizeof(float), 256);
+  w.mpart_off = w.part_off + round_up((size_t)w.ksplit * M * D * D * sizeof(float), 256);
+  // per-measure partial products of dQ / dA (M > 1 only): [M][max(N*W1, N*W2)][D]
+  w.total = w.mpart_off + (M > 1 ? round_up((u > v ? u : v) * sizeof(float), 256) : 0);
   return w;
 }
 size_t bilinear_workspace_bytes(int N, int W1, int W2, int D, int M) {
@@ -621,14 +651,26 @@ int bilinear_backward(int N, int W1, int W2, int D, int M, const float* q, const
   }
   // dQ_all = sum_m U_m W_m^T ; dA_all = sum_m V_m W_m   (:291-299; m = 0 overwrites,
   // which also realises the unconditional zeroing of :176-177)
-  for (int m = 0; m < M; ++m) {
-    const float* Wm = W + (size_t)m * D * D;
-    GemmArgs g1 = gemm_args((int)R1, D, D, U + (size_t)m * R1 * D, D, 1, Wm, 1, D, dq, D);
-    g1.beta_one = m > 0;
+  if (M == 1) {
+    GemmArgs g1 = gemm_args((int)R1, D, D, U, D, 1, W, 1, D, dq, D);
     gemm_launch(g1, 1, s);
-    GemmArgs g2 = gemm_args((int)R2, D, D, V + (size_t)m * R2 * D, D, 1, Wm, D, 1, da, D);
-    g2.beta_one = m > 0;
+    GemmArgs g2 = gemm_args((int)R2, D, D, V, D, 1, W, D, 1, da, D);
     gemm_launch(g2, 1, s);
+  } else {
+    // the M products of one operand run as ONE launch (M x the workgroups of a single product, which
+    // alone covers a fraction of the chip at the driver's sizes); their sum over m, ascending --
+    // the order the reference accumulates in -- is taken by splitk_reduce.
+    float* mpart = reinterpret_cast<float*>(base + lay.mpart_off);
+    GemmArgs g1 = gemm_args((int)R1, D, D, U, D, 1, W, 1, D, mpart, D);
+    g1.ksplit = M; g1.ks_stacked = 1; g1.a_ks = R1 * D; g1.b_ks = (long long)D * D; g1.c_ks = R1 * D;
+    gemm_launch(g1, 1, s);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks(R1 * D)), dim3(256), 0, s, mpart, M,
+                       R1 * D, dq, 0);
+    GemmArgs g2 = gemm_args((int)R2, D, D, V, D, 1, W, D, 1, mpart, D);
+    g2.ksplit = M; g2.ks_stacked = 1; g2.a_ks = R2 * D; g2.b_ks = (long long)D * D; g2.c_ks = R2 * D;
+    gemm_launch(g2, 1, s);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks(R2 * D)), dim3(256), 0, s, mpart, M,
+                       R2 * D, da, 0);
   }
   // dW_m = Q_all^T U_m  (:286-289), K = N*W1 split across workgroups; W.diff is
   // overwritten because the reference zeroes it first (:256).
