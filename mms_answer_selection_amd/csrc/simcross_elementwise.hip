@@ -640,7 +640,111 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__
 // Forward for general W1 x W2, MODE 0 (cosine; norms precomputed) or 1.
 // One wave per (pair, j-tile, k-tile); tile = (8*RJ) x (8*RK) outputs,
 // lane (lj = lane>>3, lk = lane&7) owns outputs j = j0+lj+8*rj, k = k0+lk+8*rk.
-// q/a are staged DC floats of d at a time in LDS with stride DC+1 (bank =
+//
+// CrossAcc: the register tile of one lane.  Accumulators live in packed pairs (v_pk_add_f32 /
+// v_pk_mul_f32 work on two fp32 per lane and per issue slot; each half is an ordinary IEEE op, so the
+// d-ascending sums keep their bits): columns (2p, 2p+1) of a row pair up; with RK odd the last column
+// pairs rows (2p, 2p+1); with both odd one scalar is left.
+template <int RJ, int RK, int MODE>
+struct CrossAcc {
+  static constexpr int PK = RK / 2, PJ = (RK & 1) ? RJ / 2 : 0;
+  static constexpr bool LAST = (RK & 1) && (RJ & 1);
+  float2v accp[RJ][PK > 0 ? PK : 1], accq[PJ > 0 ? PJ : 1];
+  float accs;
+
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int x = 0; x < RJ; ++x)
+#pragma unroll
+      for (int y = 0; y < (PK > 0 ? PK : 1); ++y) accp[x][y] = (float2v){0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < (PJ > 0 ? PJ : 1); ++x) accq[x] = (float2v){0.f, 0.f};
+    accs = 0.f;
+  }
+  // dn steps of d: qrow / arow point at this lane's first row of each operand in LDS (column 0 of
+  // the staged span), rows 8 apart are 8*ls floats apart
+  __device__ __forceinline__ void accumulate(const float* qrow, const float* arow, int ls, int dn) {
+    for (int dd = 0; dd < dn; ++dd) {
+      float qv[RJ], av[RK];
+#pragma unroll
+      for (int x = 0; x < RJ; ++x) qv[x] = qrow[8 * x * ls + dd];
+#pragma unroll
+      for (int y = 0; y < RK; ++y) av[y] = arow[8 * y * ls + dd];
+#pragma unroll
+      for (int x = 0; x < RJ; ++x) {
+        const float2v q2 = (float2v){qv[x], qv[x]};
+#pragma unroll
+        for (int y = 0; y < PK; ++y) {
+          const float2v a2 = (float2v){av[2 * y], av[2 * y + 1]};
+          if (MODE == 1) {
+            const float2v df = q2 - a2;
+            accp[x][y] += df * df;
+          } else {
+            accp[x][y] += q2 * a2;
+          }
+        }
+      }
+      if (PJ > 0) {
+        const float2v a2 = (float2v){av[RK - 1], av[RK - 1]};
+#pragma unroll
+        for (int x = 0; x < PJ; ++x) {
+          const float2v q2 = (float2v){qv[2 * x], qv[2 * x + 1]};
+          if (MODE == 1) {
+            const float2v df = q2 - a2;
+            accq[x] += df * df;
+          } else {
+            accq[x] += q2 * a2;
+          }
+        }
+      }
+      if (LAST) {
+        if (MODE == 1) {
+          const float df = qv[RJ - 1] - av[RK - 1];
+          accs += df * df;
+        } else {
+          accs += qv[RJ - 1] * av[RK - 1];
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ float get(int x, int y) const {
+    if (y < 2 * PK) return (y & 1) ? accp[x][y / 2].y : accp[x][y / 2].x;
+    if (x < 2 * PJ) return (x & 1) ? accq[x / 2].y : accq[x / 2].x;
+    return accs;
+  }
+  // T from the sums (:106-107 / :131-136) and the stores of this lane's outputs
+  __device__ __forceinline__ void finish(float* __restrict__ top, const float* __restrict__ norm0,
+                                         const float* __restrict__ norm1, int n, int j0, int k0,
+                                         int lj, int lk, int W1, int W2) const {
+#pragma unroll
+    for (int x = 0; x < RJ; ++x) {
+      const int j = j0 + lj + 8 * x;
+      if (j >= W1) continue;
+#pragma unroll
+      for (int y = 0; y < RK; ++y) {
+        const int k = k0 + lk + 8 * y;
+        if (k >= W2) continue;
+        float T;
+#if defined(MMS_XABL) && MMS_XABL == 1   // dev-only timing ablation (tools/crossbench.hip): no sqrt / divide
+        if (MODE == 1) {
+          T = get(x, y);
+        } else
+#endif
+        if (MODE == 1) {
+          T = 1.0f / (1.0f + sqrtf(get(x, y)));
+        } else {
+          T = get(x, y) / norm0[(size_t)n * W1 + j] / norm1[(size_t)n * W2 + k];
+        }
+#if defined(MMS_XABL) && MMS_XABL == 3   // dev-only timing ablation: no stores
+        if (T != T + 1.0f && T == 12345.678f)
+#endif
+        top[((size_t)n * W1 + j) * W2 + k] = T;
+      }
+    }
+  }
+};
+
+// Generic staging: q/a are staged DC floats of d at a time in LDS with stride DC+1 (bank =
 // (row + d) mod 32: conflict-free across rows, broadcast within a row).
 template <int RJ, int RK, int MODE>
 __global__ __launch_bounds__(256) void cross_fwd_kernel(
@@ -662,26 +766,27 @@ __global__ __launch_bounds__(256) void cross_fwd_kernel(
   const float* qn = q + (size_t)n * W1 * D;
   const float* an = a + (size_t)n * W2 * D;
 
-  float acc[RJ][RK];
-#pragma unroll
-  for (int x = 0; x < RJ; ++x)
-#pragma unroll
-    for (int y = 0; y < RK; ++y) acc[x][y] = 0.f;
+  CrossAcc<RJ, RK, MODE> acc;
+  acc.clear();
 
   const int lrow = lane >> 5, lcol = lane & 31;
-  for (int d0 = 0; d0 < D; d0 += DC) {
-    const int dn = min(DC, D - d0);
-    __syncthreads();
-    // every load is issued (clamped, hence unconditional, addresses) before the first LDS write;
-    // out-of-range elements are zeroed when written.  Written as `ok ? load : 0` the compiler
-    // emitted load / wait / write per row: 40 serialized round trips per chunk (18 of 38 us at
-    // 1517 x 40 x 40 x 50).
-    float rq[TJ / 2], ra[TK / 2];
+  // Staging: every load of a chunk is issued (clamped, hence unconditional, addresses) before the
+  // first LDS write; out-of-range elements are zeroed when written.  Written as `ok ? load : 0` the
+  // compiler emitted load / wait / write per row: 40 serialized round trips per chunk (18 of 38 us
+  // at 1517 x 40 x 40 x 50).  The NEXT chunk's loads are issued right after the LDS writes of the
+  // current one, so they are in flight behind its arithmetic.
+  float rq[TJ / 2], ra[TK / 2];
+  auto fetch = [&](int d0) {
     const int col = min(d0 + lcol, D - 1);
 #pragma unroll
     for (int r = 0; r < TJ; r += 2) rq[r / 2] = qn[(size_t)min(j0 + r + lrow, W1 - 1) * D + col];
 #pragma unroll
     for (int r = 0; r < TK; r += 2) ra[r / 2] = an[(size_t)min(k0 + r + lrow, W2 - 1) * D + col];
+  };
+  fetch(0);
+  for (int d0 = 0; d0 < D; d0 += DC) {
+    const int dn = min(DC, D - d0);
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < TJ; r += 2)
       qs[wave][(r + lrow) * LS + lcol] = (valid && j0 + r + lrow < W1 && lcol < dn) ? rq[r / 2] : 0.f;
@@ -689,43 +794,66 @@ __global__ __launch_bounds__(256) void cross_fwd_kernel(
     for (int r = 0; r < TK; r += 2)
       as[wave][(r + lrow) * LS + lcol] = (valid && k0 + r + lrow < W2 && lcol < dn) ? ra[r / 2] : 0.f;
     __syncthreads();
-    for (int dd = 0; dd < dn; ++dd) {
-      float qv[RJ], av[RK];
-#pragma unroll
-      for (int x = 0; x < RJ; ++x) qv[x] = qs[wave][(lj + 8 * x) * LS + dd];
-#pragma unroll
-      for (int y = 0; y < RK; ++y) av[y] = as[wave][(lk + 8 * y) * LS + dd];
-#pragma unroll
-      for (int x = 0; x < RJ; ++x)
-#pragma unroll
-        for (int y = 0; y < RK; ++y) {
-          if (MODE == 1) {
-            const float df = qv[x] - av[y];
-            acc[x][y] += df * df;
-          } else {
-            acc[x][y] += qv[x] * av[y];
-          }
-        }
-    }
+    if (d0 + DC < D) fetch(d0 + DC);
+#if defined(MMS_XABL) && MMS_XABL == 2   // dev-only timing ablation: no arithmetic
+    if (dn > 0) continue;
+#endif
+    acc.accumulate(&qs[wave][lj * LS], &as[wave][lk * LS], LS, dn);
   }
   if (!valid) return;
+  acc.finish(top, norm0, norm1, n, j0, k0, lj, lk, W1, W2);
+}
+
+// "Pair image" staging for small D (the driver's default 50-d vectors): a wave owns one whole pair,
+// W1 = 8*RJ and W2 = 8*RK exactly, and the (W1 x D) and (W2 x D) blocks of q and a -- contiguous in
+// memory -- are COPIED to LDS as they are, 16 bytes per lane per load, row stride D (no padding, no
+// chunking over d, no index arithmetic).  Rows 8 apart must fall into different banks for the
+// broadcast reads of accumulate(): gcd(D, 64) <= 8 (launch_cross_fwd checks).  Against the generic
+// staging at 1517 x 40 x 40 x 50 this replaces 80 4-byte load instructions and 80 predicated LDS
+// writes per wave by 16 + 16.  Waves are independent: 2 per workgroup, 32 KB of LDS each.
+// D is a template parameter: with a run-time row stride the ten row addresses of accumulate() are
+// recomputed per d step (VALU-bound loop: +15 % time); compiled in, they are immediate offsets.
+template <int RJ, int RK, int MODE, int D>
+__global__ __launch_bounds__(128) void cross_fwd_image_kernel(
+    const float* __restrict__ q, const float* __restrict__ a,
+    const float* __restrict__ norm0, const float* __restrict__ norm1,
+    float* __restrict__ top, int N) {
+  constexpr int W1 = 8 * RJ, W2 = 8 * RK;
+  extern __shared__ float4 img4[];                 // [2 waves][(W1 + W2) * D / 4]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int work = blockIdx.x * 2 + wave;
+  const bool valid = work < N;
+  const int n = valid ? work : N - 1;
+  const int nq4 = W1 * D / 4, na4 = W2 * D / 4;
+  float4* qs4 = img4 + (size_t)wave * (nq4 + na4);
+  float4* as4 = qs4 + nq4;
+  const float4* q4 = reinterpret_cast<const float4*>(q + (size_t)n * W1 * D);
+  const float4* a4 = reinterpret_cast<const float4*>(a + (size_t)n * W2 * D);
+  // copy in batches of 4 + 4 loads (all issued before the first LDS write of the batch)
+  for (int i0 = 0; i0 < max(nq4, na4); i0 += 256) {
+    float4 rq[4], ra[4];
 #pragma unroll
-  for (int x = 0; x < RJ; ++x) {
-    const int j = j0 + lj + 8 * x;
-    if (j >= W1) continue;
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 64 * u + lane;
+      rq[u] = q4[min(i, nq4 - 1)];
+      ra[u] = a4[min(i, na4 - 1)];
+    }
 #pragma unroll
-    for (int y = 0; y < RK; ++y) {
-      const int k = k0 + lk + 8 * y;
-      if (k >= W2) continue;
-      float T;
-      if (MODE == 1) {
-        T = 1.0f / (1.0f + sqrtf(acc[x][y]));
-      } else {
-        T = acc[x][y] / norm0[(size_t)n * W1 + j] / norm1[(size_t)n * W2 + k];
-      }
-      top[((size_t)n * W1 + j) * W2 + k] = T;
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 64 * u + lane;
+      if (i < nq4) qs4[i] = rq[u];
+      if (i < na4) as4[i] = ra[u];
     }
   }
+  wave_lds_sync();
+  const int lj = lane >> 3, lk = lane & 7;
+  CrossAcc<RJ, RK, MODE> acc;
+  acc.clear();
+#if !(defined(MMS_XABL) && MMS_XABL == 2)
+  acc.accumulate(reinterpret_cast<const float*>(qs4) + lj * D, reinterpret_cast<const float*>(as4) + lk * D, D, D);
+#endif
+  if (!valid) return;
+  acc.finish(top, norm0, norm1, n, 0, 0, lj, lk, W1, W2);
 }
 
 // Backward for general W1 x W2, MODE 0/1: one workgroup per pair n.  Thread
@@ -982,6 +1110,27 @@ static void launch_cross_fwd(const float* q, const float* a, const float* n0,
     if ((long long)N * tilesJ * tilesK >= 1024) break;
   }
   const long long work = (long long)N * tilesJ * tilesK;
+  // small D: the whole pair as one LDS image per wave (cross_fwd_image_kernel)
+  {
+    auto gcd64 = [](int d) { int g = 64; while (d % g) g >>= 1; return g; };
+    const size_t img = (size_t)(W1 + W2) * D * sizeof(float);
+    constexpr int DI = 50;   // the driver's default embedding width (do_trec_qa_clean.py -d 50)
+    const bool fits = W1 % 8 == 0 && W2 % 8 == 0 && W1 / 8 <= 5 && W2 / 8 <= 5 && N >= 1024 &&
+                      D == DI && aligned16(q) && aligned16(a) && gcd64(D) <= 8 && 2 * img <= 64 * 1024;
+    if (fits) {
+      const unsigned g2 = (unsigned)((N + 1) / 2);
+#define MMS_IMG_CASE(J, K)                                                                      \
+  if (W1 == 8 * J && W2 == 8 * K) {                                                             \
+    hipLaunchKernelGGL((cross_fwd_image_kernel<J, K, MODE, DI>), dim3(g2), dim3(128), 2 * img,  \
+                       s, q, a, n0, n1, top, N);                                                \
+    return;                                                                                     \
+  }
+#define MMS_IMG_ROW(J) MMS_IMG_CASE(J, 1) MMS_IMG_CASE(J, 2) MMS_IMG_CASE(J, 3) MMS_IMG_CASE(J, 4) MMS_IMG_CASE(J, 5)
+      MMS_IMG_ROW(1) MMS_IMG_ROW(2) MMS_IMG_ROW(3) MMS_IMG_ROW(4) MMS_IMG_ROW(5)
+#undef MMS_IMG_ROW
+#undef MMS_IMG_CASE
+    }
+  }
   const unsigned grid = (unsigned)((work + 3) / 4);
 #define MMS_CROSS_CASE(J, K)                                                        \
   if (rj == J && rk == K) {                                                         \

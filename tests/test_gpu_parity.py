@@ -273,6 +273,27 @@ def test_backward_without_propagate_down_zeroes_both(hiplib):
     assert (host(gq) == 0).all() and (host(ga) == 0).all()
 
 
+@pytest.mark.parametrize("shape", [(1517, 40, 40, 50), (1025, 16, 24, 50), (1031, 8, 40, 50), (1024, 40, 8, 50), (1030, 40, 40, 52)])
+def test_euclid_pair_image_forward_bitexact(shape, oracle, hiplib):
+    """Forward-only scoring of many pairs with small D (BASELINE cfg 4: the 1517 TREC-QA test
+    candidates at 40 x 40 x 50): the whole-pair LDS image kernel, ragged last workgroup included.
+    Cosine goes through the same kernel: 1e-5."""
+    from mms_answer_selection_amd import capi
+    N, W1, W2, D = shape
+    r = rng(sum(shape) + 9)
+    q, a = qa(r, N, W1, W2, D)
+    a[1, 0] = q[1, 0]
+    top_ref, _, _ = oracle.simcross_forward(1, q, a)
+    qd, ad = dev(q), dev(a)
+    top = nan_like(top_ref.shape)
+    capi.simcross_forward(1, qd, ad, top)
+    assert_bitexact(host(top), top_ref, "top")
+    ctop_ref, n0_ref, n1_ref = oracle.simcross_forward(0, q, a)
+    ctop, n0, n1 = nan_like(top_ref.shape), nan_like(n0_ref.shape), nan_like(n1_ref.shape)
+    capi.simcross_forward(0, qd, ad, ctop, norm0=n0, norm1=n1)
+    assert_close(host(ctop), ctop_ref, TOL, "cosine top")
+
+
 # --------------------------------------------------------------------------- #
 # SimCross cosine (dist_mode 0): 1e-5 (BLAS order in the reference)
 # --------------------------------------------------------------------------- #
