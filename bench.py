@@ -73,6 +73,9 @@ class Batches:
         self.dq = torch.empty_like(self.q)
         self.da = torch.empty_like(self.a)
         self.top_own = torch.empty(ring, N_PAIRS, 1, 1, 1, device="cuda")
+        if path == "cosine":
+            self.n0 = torch.empty(ring, N_PAIRS, 1, device="cuda")
+            self.n1 = torch.empty(ring, N_PAIRS, 1, device="cuda")
         if path == "triplet":
             self.an = mk(ring, N_PAIRS, 1, DIM) * 0.4
             self.y = (torch.rand(ring, N_PAIRS, 1, device="cuda", generator=g) < 0.8).float()
@@ -86,6 +89,10 @@ def make_step(capi, bt, path):
     if path == "fused":
         def step(i, top):
             capi.simcross_forward_backward(1, bt.q[i], bt.a[i], bt.dT[i], top, bt.dq[i], bt.da[i])
+    elif path == "cosine":
+        def step(i, top):
+            capi.simcross_forward_backward(0, bt.q[i], bt.a[i], bt.dT[i], top, bt.dq[i], bt.da[i],
+                                           norm0=bt.n0[i], norm1=bt.n1[i])
     elif path == "layers":
         def step(i, top):
             capi.simcross_forward(1, bt.q[i], bt.a[i], top)
@@ -380,6 +387,7 @@ def variants(torch, capi, args):
     for name, path, ring in (("fused_cold", "fused", 64), ("fused_warm", "fused", 1),
                              ("fused_cold_reference_rounding_bwd", "fused", 64),
                              ("layers_cold", "layers", 64), ("layers_warm", "layers", 1),
+                             ("cosine_fused_cold", "cosine", 64),
                              ("triplet_cold", "triplet", 48)):
         ref_mode = name.endswith("reference_rounding_bwd")
         if path == args.path and ((ring == 1) == args.warm) and not ref_mode:

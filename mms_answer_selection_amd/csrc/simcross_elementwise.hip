@@ -621,6 +621,90 @@ __global__ __launch_bounds__(256) void cosine_rows_kernel(
   }
 }
 
+// Cosine, W1=W2=1, the GloVe widths (D = 100 / 200 / 300): the data movement of
+// euclid_pair32_kernel -- 32 lanes per pair, two pairs per wave, every 16-byte load of q and a issued
+// up front and kept in registers for the backward, half-wave DPP reductions, streaming stores --
+// without the ordered chain (the reference's dot products are cblas_sdot: no defined order, 1e-5
+// contract).  The backward multiplies by per-pair factors 1/n0/n1, T/n0^2, T/n1^2 computed once
+// (IEEE divisions) instead of dividing per element (:239-245 written out costs six divisions per
+// (q_d, a_d)): a few ulp from the reference's expression, inside the same 1e-5.
+template <int D4C, bool FWD, bool BWD, int WPB>
+__global__ __launch_bounds__(64 * WPB) void cosine_pair32_kernel(
+    int N, const float* __restrict__ q, const float* __restrict__ a,
+    const float* __restrict__ top_diff, float* __restrict__ top, float* __restrict__ norm0,
+    float* __restrict__ norm1, float* __restrict__ dq, float* __restrict__ da) {
+  constexpr int NIT = (D4C + 31) / 32;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 5, j = lane & 31;
+  const int want = (blockIdx.x * WPB + wave) * 2 + grp;
+  const bool have = want < N;
+  const int row = have ? want : N - 1;
+  const float4* q4 = reinterpret_cast<const float4*>(q) + (size_t)row * D4C;
+  const float4* a4 = reinterpret_cast<const float4*>(a) + (size_t)row * D4C;
+  float4 x[NIT], y[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = j + 32 * it;
+    const int ii = i < D4C ? i : 0;              // clamp: keep the load unconditional
+    x[it] = q4[ii];
+    y[it] = a4[ii];
+  }
+  float T, n0, n1;
+  if (FWD) {
+    float sqq = 0.f, saa = 0.f, sqa = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (j + 32 * it < D4C) {
+        const float4 u = x[it], v = y[it];
+        sqq += u.x * u.x; sqq += u.y * u.y; sqq += u.z * u.z; sqq += u.w * u.w;
+        saa += v.x * v.x; saa += v.y * v.y; saa += v.z * v.z; saa += v.w * v.w;
+        sqa += u.x * v.x; sqa += u.y * v.y; sqa += u.z * v.z; sqa += u.w * v.w;
+      }
+    }
+    sqq = half_wave_sum(sqq); saa = half_wave_sum(saa); sqa = half_wave_sum(sqa);
+    n0 = sqrtf(sqq);                             // the NORM is cached, as on the CPU (:118)
+    n1 = sqrtf(saa);
+    T = sqa / n0 / n1;                           // two successive divisions (:135)
+    if (j == 0 && have) { top[row] = T; norm0[row] = n0; norm1[row] = n1; }
+  } else {
+    T = top[row]; n0 = norm0[row]; n1 = norm1[row];
+  }
+  if (!BWD) return;
+  const float g = top_diff[row];
+  const float inv01 = 1.0f / n0 / n1, cq = T / (n0 * n0), ca = T / (n1 * n1);
+  float4* dq4 = reinterpret_cast<float4*>(dq) + (size_t)row * D4C;
+  float4* da4 = reinterpret_cast<float4*>(da) + (size_t)row * D4C;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = j + 32 * it;
+    if (i < D4C && have) {
+      const float4 u = x[it], v = y[it];
+      float4 o0, o1;
+      o0.x = 0.f + g * (v.x * inv01 - u.x * cq); o0.y = 0.f + g * (v.y * inv01 - u.y * cq);
+      o0.z = 0.f + g * (v.z * inv01 - u.z * cq); o0.w = 0.f + g * (v.w * inv01 - u.w * cq);
+      o1.x = 0.f + g * (u.x * inv01 - v.x * ca); o1.y = 0.f + g * (u.y * inv01 - v.y * ca);
+      o1.z = 0.f + g * (u.z * inv01 - v.z * ca); o1.w = 0.f + g * (u.w * inv01 - v.w * ca);
+      stream_store(dq4 + i, o0);
+      stream_store(da4 + i, o1);
+    }
+  }
+}
+
+static bool pair32_width(int D);
+template <bool FWD, bool BWD>
+static void launch_cosine_pair32(const float* q, const float* a, const float* top_diff, float* top,
+                                 float* norm0, float* norm1, float* dq, float* da, int N, int D,
+                                 hipStream_t s) {
+  constexpr int WPB = 8;
+  const unsigned grid = (unsigned)((N + 2 * WPB - 1) / (2 * WPB));
+#define MMS_C32(d4)                                                                                 \
+  case 4 * d4:                                                                                      \
+    hipLaunchKernelGGL((cosine_pair32_kernel<d4, FWD, BWD, WPB>), dim3(grid), dim3(64 * WPB), 0, s, \
+                       N, q, a, top_diff, top, norm0, norm1, dq, da);                               \
+    break;
+  switch (D) { MMS_C32(25) MMS_C32(50) MMS_C32(75) }
+#undef MMS_C32
+}
+
 // ============================== cross geometry ==============================
 
 // L2 norms of `rows` rows of length D: one wave per row (cosine, general W).
@@ -1253,7 +1337,9 @@ int simcross_elementwise_forward(int mode, int N, int W1, int W2, int D,
       launch_cross_fwd<1>(q, a, nullptr, nullptr, top, N, W1, W2, D, s);
     }
   } else {
-    if (rows) {
+    if (rows && pair32_width(D) && vec4_ok(D, q, a, nullptr, nullptr)) {
+      launch_cosine_pair32<true, false>(q, a, nullptr, top, norm0, norm1, nullptr, nullptr, N, D, s);
+    } else if (rows) {
       const unsigned grid = (N + 3) / 4;
       if (vec4_ok(D, q, a, nullptr, nullptr))
         hipLaunchKernelGGL((cosine_rows_kernel<true, true, false>), dim3(grid), dim3(256), 0, s,
@@ -1288,6 +1374,9 @@ int simcross_elementwise_backward(int mode, int N, int W1, int W2, int D,
       hipLaunchKernelGGL(euclid_rows_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q, a,
                          top, top_diff, dq, da, total, D);
     }
+  } else if (rows && mode == 0 && pair32_width(D) && vec4_ok(D, q, a, dq, da)) {
+    launch_cosine_pair32<false, true>(q, a, top_diff, const_cast<float*>(top), const_cast<float*>(norm0),
+                                      const_cast<float*>(norm1), dq, da, N, D, s);
   } else if (rows && mode == 0) {
     const unsigned grid = (N + 3) / 4;
     if (vec4_ok(D, q, a, dq, da))
@@ -1340,6 +1429,10 @@ int simcross_elementwise_forward_backward(int mode, int N, int W1, int W2, int D
     const unsigned grid = (N + kRows - 1) / kRows;
     hipLaunchKernelGGL((euclid_rows_kernel<kRows, kRowsThreads, true>), dim3(grid),
                        dim3(kRowsThreads), rows_lds_bytes(D), s, q, a, top_diff, top, dq, da, N, D);
+    return launch_status();
+  }
+  if (rows && mode == 0 && pair32_width(D) && vec4_ok(D, q, a, dq, da)) {
+    launch_cosine_pair32<true, true>(q, a, top_diff, top, norm0, norm1, dq, da, N, D, s);
     return launch_status();
   }
   if (rows && mode == 0) {

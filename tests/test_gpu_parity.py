@@ -297,8 +297,8 @@ def test_euclid_pair_image_forward_bitexact(shape, oracle, hiplib):
 # --------------------------------------------------------------------------- #
 # SimCross cosine (dist_mode 0): 1e-5 (BLAS order in the reference)
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("shape", [(8, 1, 1, 300), (4096, 1, 1, 300), (9, 1, 1, 7),
-                                   (4, 5, 7, 300), (2, 40, 40, 50), (3, 41, 9, 33), (1, 70, 60, 9)])
+@pytest.mark.parametrize("shape", [(8, 1, 1, 300), (4096, 1, 1, 300), (9, 1, 1, 7), (4091, 1, 1, 200), (33, 1, 1, 100),
+                                   (17, 1, 1, 304), (4, 5, 7, 300), (2, 40, 40, 50), (3, 41, 9, 33), (1, 70, 60, 9)])
 def test_cosine_forward_backward(shape, oracle, hiplib):
     from mms_answer_selection_amd import capi
     N, W1, W2, D = shape
