@@ -514,6 +514,23 @@ def other_configs(torch, capi):
             "us_per_step": us, "pairs_per_s": N1 / (us * 1e-6), "TFLOPs": fl / us / 1e6,
             "frac_mfma_fp32_peak": fl / (us * 1e-6) / 157.3e12, "bound": "mfma / launch", "dtype": "f32"}
         del q1, a1, W1, b1, t1, dT1, dq1, da1, dW1, db1
+    # PairRankLoss alone (forward s*5*count bytes, backward s*5*count): the batch of cfg 2 and a
+    # size at which bandwidth rather than the launch floor is visible
+    for cnt in (N_PAIRS, 1 << 22):
+        pa, pb = torch.rand(cnt, 1, device="cuda", generator=g), torch.rand(cnt, 1, device="cuda", generator=g)
+        py = (torch.rand(cnt, 1, device="cuda", generator=g) < 0.2).float()
+        po, ps = torch.empty_like(pa), torch.empty_like(pa)
+        pl = torch.empty(1, device="cuda")
+        pda, pdb = torch.empty_like(pa), torch.empty_like(pa)
+
+        def prl():
+            capi.pairrank_forward(pa, pb, py, po, ps, pl, margin=0.1, ws=ws)
+            capi.pairrank_backward(py, po, ps, pda, pdb)
+        us = _graph_time(torch, prl, iters=8)
+        out["pairrankloss_%dx1_fwd_bwd" % cnt] = {
+            "us_per_step": us, "pairs_per_s": cnt / (us * 1e-6),
+            "frac_hbm_unfused_bytes": 4.0 * 10 * cnt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": "hbm / launch"}
+        del pa, pb, py, po, ps, pl, pda, pdb
     # cfg 5 shard: 8192 pairs x 1024-d, fp16 storage, fused fwd+bwd (one launch)
     N, D = 8192, 1024
     qh, ah = rnd(N, 1, D).half(), rnd(N, 1, D).half()
