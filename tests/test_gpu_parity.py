@@ -365,10 +365,41 @@ def test_bilinear_forward_backward(cfg, oracle, hiplib):
         assert_bitexact(host(gb), db_ref, "dbias (accumulated, n ascending)")
 
 
+def test_bilinear_shape_fuzz(oracle, hiplib):
+    """Random geometries through every GEMM dispatch branch: 16-byte rows (D % 4 == 0), 8-byte rows
+    (D % 4 == 2: the driver's default D = 50), odd D (stride-generic kernel), one or several measures
+    (stacked split-K over m), W1 != W2, batch sizes on both sides of the deep-k-tile threshold."""
+    from mms_answer_selection_amd import capi
+    r = rng(77)
+    shapes = [(50, 40, 40, 50, 4), (32, 40, 40, 300, 4), (70, 24, 40, 50, 3), (600, 1, 1, 50, 2)]
+    for _ in range(10):
+        shapes.append((int(r.integers(1, 40)), int(r.integers(1, 45)), int(r.integers(1, 45)),
+                       int(r.choice([6, 10, 12, 18, 20, 33, 50, 64, 100])), int(r.integers(1, 5))))
+    for (N, W1, W2, D, M) in shapes:
+        q, a = qa(r, N, W1, W2, D)
+        W = r.uniform(-0.08, 0.08, (M, D, D)).astype(np.float32)
+        bias = r.standard_normal((M, W1, W2)).astype(np.float32)
+        dT = r.standard_normal((N, M, W1, W2)).astype(np.float32)
+        db0 = r.standard_normal((M, W1, W2)).astype(np.float32)
+        top_ref, _, _ = oracle.simcross_forward(2, q, a, W, bias)
+        dq_ref, da_ref, dW_ref, db_ref = oracle.simcross_backward(2, q, a, top_ref, dT, W=W, bias_term=True,
+                                                                  dbias_in=db0)
+        qd, ad, Wd, bd, dTd = dev(q), dev(a), dev(W), dev(bias), dev(dT)
+        top, gq, ga, gW, gb = nan_like(top_ref.shape), nan_like(q.shape), nan_like(a.shape), nan_like(W.shape), dev(db0)
+        capi.simcross_forward(2, qd, ad, top, W=Wd, bias=bd)
+        capi.simcross_backward(2, qd, ad, top, dTd, gq, ga, W=Wd, bias_term=True, dW=gW, dbias=gb)
+        what = "shape %s " % ((N, W1, W2, D, M),)
+        assert_close(host(top), top_ref, TOL, what + "top")
+        assert_close(host(gq), dq_ref, TOL, what + "dq")
+        assert_close(host(ga), da_ref, TOL, what + "da")
+        assert_close(host(gW), dW_ref, TOL, what + "dW")
+        assert_bitexact(host(gb), db_ref, what + "dbias")
+
+
 # --------------------------------------------------------------------------- #
 # SimMatrix: 1e-5
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("shape", [(16, 300, 300), (5, 7, 3), (700, 64, 48), (1, 1, 1)])
+@pytest.mark.parametrize("shape", [(16, 300, 300), (5, 7, 3), (700, 64, 48), (1, 1, 1), (900, 50, 50), (130, 33, 18), (2100, 12, 300)])
 def test_simmatrix(shape, oracle, hiplib):
     from mms_answer_selection_amd import capi
     N, K1, K2 = shape
