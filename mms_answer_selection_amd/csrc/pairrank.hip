@@ -109,6 +109,36 @@ static int pair_blocks(int count) {
   if (b > 1024) b = 1024;
   return b;
 }
+// Batches of at most 8192 elements (the reference's use: one score column of 50 .. 4096 pairs) in ONE
+// launch: a single 1024-thread workgroup, up to eight elements per thread with all 24 loads issued
+// before the first use, fixed-order block sum.  Saves the separate loss-finish launch.
+constexpr int kSmallThreads = 1024, kSmallMax = 8 * kSmallThreads;
+__global__ __launch_bounds__(kSmallThreads) void pairrank_fwd_small_kernel(
+    int count, float margin, const float* __restrict__ a, const float* __restrict__ b,
+    const float* __restrict__ y, float* __restrict__ ordered, float* __restrict__ similar,
+    float* __restrict__ loss) {
+  __shared__ float red[kSmallThreads / 64];
+  float va[8], vb[8], vy[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int i = threadIdx.x + u * kSmallThreads;
+    const int ii = i < count ? i : 0;
+    va[u] = a[ii]; vb[u] = b[ii]; vy[u] = y[ii];
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int i = threadIdx.x + u * kSmallThreads;
+    if (i < count) {
+      const PairTerm p = pair_term(va[u], vb[u], vy[u], margin);
+      ordered[i] = p.ordered;
+      similar[i] = p.similar;
+      s += p.term;
+    }
+  }
+  s = block_sum<kSmallThreads>(s, red);
+  if (threadIdx.x == 0) *loss = s / (float)count;   // :49
+}
 
 size_t pairrank_workspace_bytes(int count) {
   const int b = pair_blocks(count);
@@ -118,6 +148,11 @@ size_t pairrank_workspace_bytes(int count) {
 int pairrank_forward(int count, float margin, const float* a, const float* b, const float* y,
                      float* ordered, float* similar, float* loss, void* ws, size_t ws_bytes,
                      hipStream_t s) {
+  if (count <= kSmallMax) {
+    hipLaunchKernelGGL(pairrank_fwd_small_kernel, dim3(1), dim3(kSmallThreads), 0, s, count, margin, a,
+                       b, y, ordered, similar, loss);
+    return launch_status();
+  }
   const int blocks = pair_blocks(count);
   if (blocks > 1 && (ws == nullptr || ws_bytes < (size_t)blocks * sizeof(float)))
     return MMS_ERR_WORKSPACE;
