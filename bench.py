@@ -554,6 +554,24 @@ def other_configs(torch, capi):
         out[name] = {"us_per_step": us, "pairs_per_s": n / (us * 1e-6), "GBps_algorithmic": b / us / 1e3,
                      "bound": "fp32 VALU (3 flop per (j,k,d), d-ordered sums)"}
         del qg, ag, tg
+    # the same scores from WORD IDS: Embed (50-d table, 20,000 words) then SimCross, and the fused call
+    n, K = 1517, 20000
+    tab = rnd(K, 50)
+    iq = torch.randint(0, K, (n, 40), device="cuda", generator=g).float()
+    ia = torch.randint(0, K, (n, 40), device="cuda", generator=g).float()
+    qe, ae = torch.empty(n, 40, 50, device="cuda"), torch.empty(n, 40, 50, device="cuda")
+    tg = torch.empty(n, 1, 40, 40, device="cuda")
+
+    def embed_then_score():
+        capi.embed_forward(iq, tab, qe.view(-1, 50))
+        capi.embed_forward(ia, tab, ae.view(-1, 50))
+        capi.simcross_forward(1, qe, ae, tg)
+    us2 = _graph_time(torch, embed_then_score)
+    us1 = _graph_time(torch, lambda: capi.embed_simcross_forward(1, iq, ia, tab, tg))
+    out["cfg4_scoring_from_word_ids_1517x40x40x50"] = {
+        "us_per_step_embed_then_simcross": us2, "us_per_step_fused": us1, "pairs_per_s": n / (us1 * 1e-6),
+        "note": "Embed gather fused into SimCross's loads (mms_embed_simcross_forward_f32) vs three launches"}
+    del tab, iq, ia, qe, ae, tg
     n = 1517
     sc = torch.rand(n, device="cuda", generator=g)
     prob = torch.stack([1 - sc, sc], 1).contiguous()

@@ -276,6 +276,20 @@ int mms_embed_backward_f32(int M, int N, int K, const float* index, const float*
 
 size_t mms_embed_workspace_bytes(int M, int N);
 
+/* Embed fused into SimCross's loads (forward / scoring; dist_mode 0 or 1):
+ *   top == SimCross(Embed(index_q), Embed(index_a))
+ * i.e. embed_layer.cpp:135-152 (bias_term false, as the driver's embedding layers are,
+ * examples/trec_qa_w2v_mms/do_trec_qa_clean.py:462) followed by sim_cross_layer.cpp:96-139,
+ * without the (N,W,D) blobs in between.  index_q (N,W1) and index_a (N,W2) hold word ids as
+ * floats, clamped into [0,K) like mms_embed_forward_f32; weight (K,D); top (N,1,W1,W2);
+ * norm0 (N,W1) / norm1 (N,W2) receive the row norms in dist_mode 0 (NULL otherwise).  Results
+ * are the bits of the two separate calls (Euclid: the reference's CPU bits).  dist_mode 2
+ * returns MMS_ERR_UNSUPPORTED: run mms_embed_forward_f32, then mms_simcross_forward_f32. */
+int mms_embed_simcross_forward_f32(int dist_mode, int N, int W1, int W2, int D, int K,
+                                   const float* index_q, const float* index_a,
+                                   const float* weight, float* top, float* norm0,
+                                   float* norm1, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Batch feed: dst[i,:] = src[perm[first+i],:], i < rows,
  * for a dataset (src_rows, row_elems) resident in HBM; perm (src_rows ints on

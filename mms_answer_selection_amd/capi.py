@@ -25,6 +25,7 @@ _SIGNATURES = {
     "mms_simcross_backward_f32": (_i, [_i] * 6 + [_vp] * 3 + [_i] + [_vp] * 4 + [_i, _i] + [_vp] * 5 + [_sz, _vp]),
     "mms_simcross_forward_backward_f32": (_i, [_i] * 6 + [_vp] * 13 + [_sz, _vp]),
     "mms_simmatrix_workspace_bytes": (_sz, [_i] * 3),
+    "mms_embed_simcross_forward_f32": (_i, [_i] * 6 + [_vp] * 7),
     "mms_simmatrix_forward_f32": (_i, [_i] * 3 + [_vp] * 6),
     "mms_simmatrix_backward_f32": (_i, [_i] * 3 + [_vp] * 4 + [_i] * 3 + [_vp] * 4 + [_sz, _vp]),
     "mms_simmatrix_backward_cached_f32": (_i, [_i] * 3 + [_vp] * 5 + [_i] * 3 + [_vp] * 4 + [_sz, _vp]),
@@ -160,6 +161,17 @@ def simcross_forward_backward(mode, q, a, top_diff, top, dq, da, W=None, bias=No
         _ptr(norm0, "norm0", True), _ptr(norm1, "norm1", True), _ptr(dq, "dq"), _ptr(da, "da"),
         _ptr(dW, "dW", True), _ptr(dbias, "dbias", True), wsp, wsb, _stream()),
         "mms_simcross_forward_backward_f32")
+
+
+def embed_simcross_forward(mode, index_q, index_a, weight, top, norm0=None, norm1=None):
+    """top = SimCross(Embed(index_q), Embed(index_a)), dist_mode 0 / 1, the gather fused into the loads."""
+    N, W1 = index_q.shape[0], index_q.shape[1]
+    W2 = index_a.shape[1]
+    K, D = weight.shape
+    check(lib().mms_embed_simcross_forward_f32(
+        mode, N, W1, W2, D, K, _ptr(index_q, "index_q"), _ptr(index_a, "index_a"), _ptr(weight, "weight"),
+        _ptr(top, "top"), _ptr(norm0, "norm0", True), _ptr(norm1, "norm1", True), _stream()),
+        "mms_embed_simcross_forward_f32")
 
 
 def simmatrix_forward(q, a, W, top, qw_scratch):

@@ -708,13 +708,21 @@ static void launch_cosine_pair32(const float* q, const float* a, const float* to
 // ============================== cross geometry ==============================
 
 // L2 norms of `rows` rows of length D: one wave per row (cosine, general W).
+// Word id stored as a float (Caffe feeds ids as Dtype), clamped into the table like embed_fwd_kernel.
+__device__ __forceinline__ int gather_id(float v, int K) {
+  const int i = (int)v;
+  return i < 0 ? 0 : (i >= K ? K - 1 : i);
+}
+
+// index != nullptr: row `row` is table row index[row] of x (K rows) -- the Embed gather fused in.
 __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ x,
                                                        float* __restrict__ nrm,
-                                                       long long rows, int D) {
+                                                       long long rows, int D,
+                                                       const float* __restrict__ index, int K) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* r = x + row * D;
+  const float* r = x + (index ? (long long)gather_id(index[row], K) : row) * D;
   float s = 0.f;
   for (int i = lane; i < D; i += 64) s += r[i] * r[i];
   s = wave_sum(s);
@@ -828,16 +836,26 @@ struct CrossAcc {
   }
 };
 
+// Embed fused into the load: with iq != nullptr, q and a are both the embedding
+// TABLE (K x D) and row j of pair n is table row iq[n*W1 + j] (ia likewise) -- the (N, W, D) blobs
+// the Embed layer would write and SimCross read back never exist.
+struct CrossGather {
+  const float* iq;
+  const float* ia;
+  int K;
+};
+
 // Generic staging: q/a are staged DC floats of d at a time in LDS with stride DC+1 (bank =
 // (row + d) mod 32: conflict-free across rows, broadcast within a row).
 template <int RJ, int RK, int MODE>
 __global__ __launch_bounds__(256) void cross_fwd_kernel(
     const float* __restrict__ q, const float* __restrict__ a,
     const float* __restrict__ norm0, const float* __restrict__ norm1,
-    float* __restrict__ top, int N, int W1, int W2, int D, int tilesJ, int tilesK) {
+    float* __restrict__ top, int N, int W1, int W2, int D, int tilesJ, int tilesK, CrossGather gt) {
   constexpr int TJ = 8 * RJ, TK = 8 * RK, DC = 32, LS = DC + 1;
   __shared__ float qs[4][TJ * LS];
   __shared__ float as[4][TK * LS];
+  __shared__ int rowoff[4][TJ + TK];               // gather: element offset of each tile row in the table
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long work = (long long)blockIdx.x * 4 + wave;
   const long long total = (long long)N * tilesJ * tilesK;
@@ -860,8 +878,25 @@ __global__ __launch_bounds__(256) void cross_fwd_kernel(
   // at 1517 x 40 x 40 x 50).  The NEXT chunk's loads are issued right after the LDS writes of the
   // current one, so they are in flight behind its arithmetic.
   float rq[TJ / 2], ra[TK / 2];
+  const bool gather = gt.iq != nullptr;
+  if (gather) {                                  // word ids of this tile's rows -> table offsets, once
+    for (int r = lane; r < TJ + TK; r += 64) {
+      const bool isq = r < TJ;
+      const int rr = isq ? min(j0 + r, W1 - 1) : min(k0 + r - TJ, W2 - 1);
+      const float id = isq ? gt.iq[(size_t)n * W1 + rr] : gt.ia[(size_t)n * W2 + rr];
+      rowoff[wave][r] = gather_id(id, gt.K) * D;
+    }
+    wave_lds_sync();
+  }
   auto fetch = [&](int d0) {
     const int col = min(d0 + lcol, D - 1);
+    if (gather) {
+#pragma unroll
+      for (int r = 0; r < TJ; r += 2) rq[r / 2] = q[(size_t)rowoff[wave][r + lrow] + col];
+#pragma unroll
+      for (int r = 0; r < TK; r += 2) ra[r / 2] = a[(size_t)rowoff[wave][TJ + r + lrow] + col];
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < TJ; r += 2) rq[r / 2] = qn[(size_t)min(j0 + r + lrow, W1 - 1) * D + col];
 #pragma unroll
@@ -901,7 +936,7 @@ template <int RJ, int RK, int MODE, int D>
 __global__ __launch_bounds__(128) void cross_fwd_image_kernel(
     const float* __restrict__ q, const float* __restrict__ a,
     const float* __restrict__ norm0, const float* __restrict__ norm1,
-    float* __restrict__ top, int N) {
+    float* __restrict__ top, int N, CrossGather gt) {
   constexpr int W1 = 8 * RJ, W2 = 8 * RK;
   extern __shared__ float4 img4[];                 // [2 waves][(W1 + W2) * D / 4]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -913,6 +948,39 @@ __global__ __launch_bounds__(128) void cross_fwd_image_kernel(
   float4* as4 = qs4 + nq4;
   const float4* q4 = reinterpret_cast<const float4*>(q + (size_t)n * W1 * D);
   const float4* a4 = reinterpret_cast<const float4*>(a + (size_t)n * W2 * D);
+  if (gt.iq != nullptr) {
+    // Embed fused in: image row r is table row id[r]; rows are D floats = 8-byte aligned for even D, so
+    // the copy runs in float2.  Per batch: the ids of 8 + 8 elements, then their 16 loads, then the writes.
+    constexpr int R2 = D / 2;                      // float2 per row
+    float2* qs2 = reinterpret_cast<float2*>(qs4);
+    float2* as2 = reinterpret_cast<float2*>(as4);
+    const float2* t2 = reinterpret_cast<const float2*>(q);
+    const float* iq = gt.iq + (size_t)n * W1;
+    const float* ia = gt.ia + (size_t)n * W2;
+    constexpr int NQ2 = W1 * R2, NA2 = W2 * R2, NMAX = NQ2 > NA2 ? NQ2 : NA2;
+    for (int e0 = 0; e0 < NMAX; e0 += 512) {
+      float idq[8], ida[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 64 * u + lane;
+        idq[u] = iq[min(e, NQ2 - 1) / R2];
+        ida[u] = ia[min(e, NA2 - 1) / R2];
+      }
+      float2 rq[8], ra[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 64 * u + lane;
+        rq[u] = t2[(size_t)gather_id(idq[u], gt.K) * R2 + min(e, NQ2 - 1) % R2];
+        ra[u] = t2[(size_t)gather_id(ida[u], gt.K) * R2 + min(e, NA2 - 1) % R2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 64 * u + lane;
+        if (e < NQ2) qs2[e] = rq[u];
+        if (e < NA2) as2[e] = ra[u];
+      }
+    }
+  } else
   // copy in batches of 4 + 4 loads (all issued before the first LDS write of the batch)
   for (int i0 = 0; i0 < max(nq4, na4); i0 += 256) {
     float4 rq[4], ra[4];
@@ -1183,7 +1251,7 @@ static size_t cross_bwd_tiled_lds(int mode, int W1, int W2) {
 template <int MODE>
 static void launch_cross_fwd(const float* q, const float* a, const float* n0,
                              const float* n1, float* top, int N, int W1, int W2,
-                             int D, hipStream_t s) {
+                             int D, hipStream_t s, CrossGather gt = CrossGather{nullptr, nullptr, 0}) {
   // Register tile per lane: as large as possible (fewer LDS reads per flop) while the
   // launch still has enough waves to occupy the chip (small N: smaller tiles, more waves).
   auto r_cap = [](int w, int cap) { int r = (w + 7) / 8; return r > cap ? cap : r; };
@@ -1201,12 +1269,13 @@ static void launch_cross_fwd(const float* q, const float* a, const float* n0,
     constexpr int DI = 50;   // the driver's default embedding width (do_trec_qa_clean.py -d 50)
     const bool fits = W1 % 8 == 0 && W2 % 8 == 0 && W1 / 8 <= 5 && W2 / 8 <= 5 && N >= 1024 &&
                       D == DI && aligned16(q) && aligned16(a) && gcd64(D) <= 8 && 2 * img <= 64 * 1024;
+    static_assert(DI % 2 == 0, "gather copies float2");
     if (fits) {
       const unsigned g2 = (unsigned)((N + 1) / 2);
 #define MMS_IMG_CASE(J, K)                                                                      \
   if (W1 == 8 * J && W2 == 8 * K) {                                                             \
     hipLaunchKernelGGL((cross_fwd_image_kernel<J, K, MODE, DI>), dim3(g2), dim3(128), 2 * img,  \
-                       s, q, a, n0, n1, top, N);                                                \
+                       s, q, a, n0, n1, top, N, gt);                                            \
     return;                                                                                     \
   }
 #define MMS_IMG_ROW(J) MMS_IMG_CASE(J, 1) MMS_IMG_CASE(J, 2) MMS_IMG_CASE(J, 3) MMS_IMG_CASE(J, 4) MMS_IMG_CASE(J, 5)
@@ -1219,7 +1288,7 @@ static void launch_cross_fwd(const float* q, const float* a, const float* n0,
 #define MMS_CROSS_CASE(J, K)                                                        \
   if (rj == J && rk == K) {                                                         \
     hipLaunchKernelGGL((cross_fwd_kernel<J, K, MODE>), dim3(grid), dim3(256), 0, s, \
-                       q, a, n0, n1, top, N, W1, W2, D, tilesJ, tilesK);            \
+                       q, a, n0, n1, top, N, W1, W2, D, tilesJ, tilesK, gt);        \
     return;                                                                         \
   }
 #define MMS_CROSS_ROW(J) MMS_CROSS_CASE(J, 1) MMS_CROSS_CASE(J, 2) MMS_CROSS_CASE(J, 3) \
@@ -1349,10 +1418,29 @@ int simcross_elementwise_forward(int mode, int N, int W1, int W2, int D,
                            q, a, nullptr, top, norm0, norm1, nullptr, nullptr, N, D);
     } else {
       const long long r0 = (long long)N * W1, r1 = (long long)N * W2;
-      hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)((r0 + 3) / 4)), dim3(256), 0, s, q, norm0, r0, D);
-      hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)((r1 + 3) / 4)), dim3(256), 0, s, a, norm1, r1, D);
+      hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)((r0 + 3) / 4)), dim3(256), 0, s, q, norm0, r0, D, nullptr, 0);
+      hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)((r1 + 3) / 4)), dim3(256), 0, s, a, norm1, r1, D, nullptr, 0);
       launch_cross_fwd<0>(q, a, norm0, norm1, top, N, W1, W2, D, s);
     }
+  }
+  return launch_status();
+}
+
+// top = SimCross(Embed(index_q), Embed(index_a)) for dist_mode 0 / 1, no Embed bias (the driver's
+// embedding layers have bias_term false, do_trec_qa_clean.py:462): embed_layer.cpp:135-152 followed by
+// sim_cross_layer.cpp:96-139, with the gather done by SimCross's own loads.
+int embed_simcross_forward(int mode, int N, int W1, int W2, int D, int K, const float* index_q,
+                           const float* index_a, const float* weight, float* top, float* norm0,
+                           float* norm1, hipStream_t s) {
+  if (N == 0) return MMS_OK;
+  const CrossGather gt{index_q, index_a, K};
+  if (mode == 1) {
+    launch_cross_fwd<1>(weight, weight, nullptr, nullptr, top, N, W1, W2, D, s, gt);
+  } else {
+    const long long r0 = (long long)N * W1, r1 = (long long)N * W2;
+    hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)((r0 + 3) / 4)), dim3(256), 0, s, weight, norm0, r0, D, index_q, K);
+    hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)((r1 + 3) / 4)), dim3(256), 0, s, weight, norm1, r1, D, index_a, K);
+    launch_cross_fwd<0>(weight, weight, norm0, norm1, top, N, W1, W2, D, s, gt);
   }
   return launch_status();
 }

@@ -45,6 +45,42 @@ def test_embed_forward_backward(cfg, oracle, hiplib):
     assert_bitexact(wd2.cpu().numpy(), wd_ref)
 
 
+@pytest.mark.parametrize("cfg", [(1517, 40, 40, 50, 20000), (1100, 16, 24, 50, 300), (7, 40, 40, 50, 100),
+                                 (5, 9, 13, 33, 40), (3, 40, 40, 300, 500), (600, 1, 1, 20, 64)])
+def test_embed_fused_into_simcross_forward(cfg, oracle, hiplib):
+    """mms_embed_simcross_forward_f32 == Embed (no bias) followed by SimCross: Euclidean scores carry the
+    CPU's bits; cosine 1e-5.  Covers the pair-image kernel (many pairs, D = 50) and the generic tiles."""
+    from mms_answer_selection_amd import capi
+    N, W1, W2, D, K = cfg
+    r = rng(sum(cfg))
+    weight = r.uniform(-0.5, 0.5, (K, D)).astype(np.float32)
+    iq = r.integers(0, K, (N, W1)).astype(np.float32)
+    ia = r.integers(0, K, (N, W2)).astype(np.float32)
+    ia[r.uniform(size=ia.shape) < 0.4] = K - 1          # zero-pad id
+    if N > 2:
+        ia[1, 0] = iq[1, 0]                              # identical rows: T = 1
+    q = oracle.embed_forward(iq.reshape(-1), weight, None).reshape(N, W1, D)
+    a = oracle.embed_forward(ia.reshape(-1), weight, None).reshape(N, W2, D)
+    top_ref, _, _ = oracle.simcross_forward(1, q, a)
+    top = torch.full(top_ref.shape, float("nan"), device="cuda")
+    capi.embed_simcross_forward(1, dev(iq), dev(ia), dev(weight), top)
+    assert_bitexact(top.cpu().numpy(), top_ref, "Euclid scores of the fused call")
+    ctop_ref, n0_ref, n1_ref = oracle.simcross_forward(0, q, a)
+    ctop = torch.full(top_ref.shape, float("nan"), device="cuda")
+    n0 = torch.full(n0_ref.shape, float("nan"), device="cuda")
+    n1 = torch.full(n1_ref.shape, float("nan"), device="cuda")
+    capi.embed_simcross_forward(0, dev(iq), dev(ia), dev(weight), ctop, norm0=n0, norm1=n1)
+    assert_close(ctop.cpu().numpy(), ctop_ref, TOL, "cosine scores of the fused call")
+    assert_close(n0.cpu().numpy(), n0_ref, TOL, "norm0")
+    # ids outside the table are clamped like mms_embed_forward_f32
+    iq2 = iq.copy(); iq2[0, 0] = -3.0; iq2[-1, -1] = K + 5.0
+    iq2c = iq2.copy(); iq2c[0, 0] = 0.0; iq2c[-1, -1] = K - 1.0
+    t1 = torch.empty_like(top); t2 = torch.empty_like(top)
+    capi.embed_simcross_forward(1, dev(iq2), dev(ia), dev(weight), t1)
+    capi.embed_simcross_forward(1, dev(iq2c), dev(ia), dev(weight), t2)
+    assert_bitexact(t1.cpu().numpy(), t2.cpu().numpy(), "clamped ids")
+
+
 def test_embed_layer_weight_sources_and_chain(tmp_path, oracle, hiplib):
     from mms_answer_selection_amd import layers as L
     L.lib(); L.set_mode_gpu()
