@@ -78,6 +78,14 @@ def test_feed_embed_simcross_ranking_pipeline(tmp_path, oracle, hiplib):
         grid_ref, _, _ = oracle.simcross_forward(1, q_ref, a_ref)
         assert tgrid.data.shape == (B, 1, Lw, Lw)
         assert_bitexact(tgrid.data, grid_ref, "word-grid scores")
+        # the same grid straight from the fed word ids: Embed fused into SimCross's loads (C ABI)
+        import torch
+        from mms_answer_selection_amd import capi
+        ids_q = torch.from_numpy(tq.data.reshape(B, Lw).copy()).cuda()
+        ids_a = torch.from_numpy(ta.data.reshape(B, Lw).copy()).cuda()
+        fused = torch.empty(B, 1, Lw, Lw, device="cuda")
+        capi.embed_simcross_forward(1, ids_q, ids_a, torch.from_numpy(table).cuda(), fused)
+        assert_bitexact(fused.cpu().numpy(), grid_ref, "word-grid scores from word ids (fused call)")
         # sentence vectors (sum of word vectors in d-order on the host) -> one score per candidate
         qs = q_ref.sum(axis=1, dtype=np.float32).reshape(B, 1, Dw)
         as_ = a_ref.sum(axis=1, dtype=np.float32).reshape(B, 1, Dw)
