@@ -206,36 +206,19 @@ constexpr int FM = 64, FN = 64, LSJ = FN + 4;
 
 // VW = floats per global load: 4 (16-byte-aligned rows, e.g. D = 300 / 1024) or 2 (8-byte-aligned rows:
 // the driver's default D = 50, whose rows are 200 bytes).
-template <bool A_KVEC, bool B_JVEC, bool KSCALE, int FK, int VW>
-__global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
+// One 64x64 output tile of one product.  AKT / BJT: 1 or 0 fix the operand layouts at compile time (the
+// single-product kernel below), -1 takes them from rt_ak / rt_bj (the grouped kernel, whose problems differ).
+template <int AKT, int BJT, bool KSCALE, int FK, int VW>
+__device__ __forceinline__ void gemm32_fast_tile(const GemmArgs& g, int bx, int by, int z, bool rt_ak,
+                                                 bool rt_bj, float* As2base, float* Bs2base) {
+  const bool A_KVEC = AKT < 0 ? rt_ak : (AKT != 0);
+  const bool B_JVEC = BJT < 0 ? rt_bj : (BJT != 0);
   typedef float VT __attribute__((ext_vector_type(VW)));
   constexpr int LSK = FK + 4;
   constexpr int FSL = FK / (4 * VW);   // vector load slots per operand per thread per tile
   constexpr int KV = FK / VW;          // vectors along the k extent of a tile
   constexpr int JV = 64 / VW;          // vectors along the 64-wide extent of a tile
   constexpr int FH = FK / 2;           // k values per half-wave per tile
-  __shared__ float As2[2][FM * LSK];            // double-buffered: one barrier per k-tile
-  __shared__ float Bs2[2][FK * LSJ];
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own
-  // L2) in linear-id order (x fastest, then y, then z), so linear ids that differ by 8 share an L2.
-  // Remap so that CONSECUTIVE logical tiles land on one XCD: the column tiles of one row panel
-  // (they re-read the same A rows), and -- for a split-K product -- all tiles of one k-chunk (each
-  // re-reads the chunk's A and B slabs; dealt over 8 L2s those slabs came from HBM 6 times over).
-  MMS_GSTAMP(0);
-  MMS_GSTAMP_REAL(4);
-  MMS_GSTAMP_WHERE();
-  int bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
-  {
-    const int plane = gridDim.x * gridDim.y, total = plane * gridDim.z;
-    if ((total & 7) == 0) {
-      const int id = z * plane + by * gridDim.x + bx;
-      int tl = (id & 7) * (total >> 3) + (id >> 3);
-      z = tl / plane;
-      tl -= z * plane;
-      by = tl / gridDim.x;
-      bx = tl - by * gridDim.x;
-    }
-  }
   const int ks = z % g.ksplit;
   const int b1 = (z / g.ksplit) % g.nb1;
   const int b0 = (z / g.ksplit) / g.nb1;
@@ -294,8 +277,8 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
     }
   };
   auto store = [&](int buf) {
-    float* As = As2[buf];
-    float* Bs = Bs2[buf];
+    float* As = As2base + buf * (FM * LSK);
+    float* Bs = Bs2base + buf * (FK * LSJ);
     const VT zv = 0.f;
 #pragma unroll
     for (int sl = 0; sl < FSL; ++sl) {
@@ -331,8 +314,8 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
     for (int k0 = kbeg; k0 < kend; k0 += FK, cur ^= 1) {
       const bool more = k0 + FK < kend;
       if (more) load(k0 + FK);                    // global -> registers, in flight behind the MFMAs
-      const float* As = As2[cur];
-      const float* Bs = Bs2[cur];
+      const float* As = As2base + cur * (FM * LSK);
+      const float* Bs = Bs2base + cur * (FK * LSJ);
       const float4* arow = reinterpret_cast<const float4*>(&As[(wm * 32 + r) * LSK + FH * h]);
       float av[FH], bv[FH];
 #pragma unroll
@@ -370,6 +353,65 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
 #endif
   MMS_GSTAMP(3);
   MMS_GSTAMP_REAL(5);
+}
+
+
+template <bool A_KVEC, bool B_JVEC, bool KSCALE, int FK, int VW>
+__global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
+  __shared__ float As2[2 * FM * (FK + 4)];      // double-buffered: one barrier per k-tile
+  __shared__ float Bs2[2 * FK * LSJ];
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own
+  // L2) in linear-id order (x fastest, then y, then z), so linear ids that differ by 8 share an L2.
+  // Remap so that CONSECUTIVE logical tiles land on one XCD: the column tiles of one row panel
+  // (they re-read the same A rows), and -- for a split-K product -- all tiles of one k-chunk (each
+  // re-reads the chunk's A and B slabs; dealt over 8 L2s those slabs came from HBM 6 times over).
+  MMS_GSTAMP(0);
+  MMS_GSTAMP_REAL(4);
+  MMS_GSTAMP_WHERE();
+  int bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
+  {
+    const int plane = gridDim.x * gridDim.y, total = plane * gridDim.z;
+    if ((total & 7) == 0) {
+      const int id = z * plane + by * gridDim.x + bx;
+      int tl = (id & 7) * (total >> 3) + (id >> 3);
+      z = tl / plane;
+      tl -= z * plane;
+      by = tl / gridDim.x;
+      bx = tl - by * gridDim.x;
+    }
+  }
+  gemm32_fast_tile<A_KVEC ? 1 : 0, B_JVEC ? 1 : 0, KSCALE, FK, VW>(g, bx, by, z, false, false, As2, Bs2);
+}
+
+// Several SMALL products in one launch (the driver's batch of 50 pairs makes every product of the bilinear
+// backward a 5-8 us launch at the latency floor: U and V, then dQ, dA and dW, are independent of each
+// other).  Workgroup w of the 1-D grid belongs to the problem whose [first, first + count) holds w; operand
+// layouts are run-time flags.  No XCD remapping: the problems are small by construction.
+constexpr int kGroupMax = 3;
+struct GemmGroup {
+  GemmArgs g[kGroupMax];
+  int first[kGroupMax + 1];      // first workgroup of each problem; first[n] = total
+  int gx[kGroupMax], gy[kGroupMax];
+  int ak[kGroupMax], bj[kGroupMax];
+  int n;
+};
+
+template <int FK, int VW>
+__global__ __launch_bounds__(256) void gemm32_group_kernel(GemmGroup grp) {
+  __shared__ float As2[2 * FM * (FK + 4)];
+  __shared__ float Bs2[2 * FK * LSJ];
+  const int w = blockIdx.x;
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < kGroupMax; ++i)
+    if (i < grp.n && w >= grp.first[i]) p = i;
+  int l = w - grp.first[p];
+  const int plane = grp.gx[p] * grp.gy[p];
+  const int z = l / plane;
+  l -= z * plane;
+  const int by = l / grp.gx[p], bx = l - by * grp.gx[p];
+  // p is uniform: the struct members come from the kernarg segment with scalar loads at a computed offset
+  gemm32_fast_tile<-1, -1, false, FK, VW>(grp.g[p], bx, by, z, grp.ak[p] != 0, grp.bj[p] != 0, As2, Bs2);
 }
 
 static bool multv(long long x, int vw) { return x % vw == 0; }
@@ -447,6 +489,73 @@ static void gemm_launch(const GemmArgs& g0, int nb0, hipStream_t s) {
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, nb * per_b0);
     hipLaunchKernelGGL(gemm32_kernel, grid, dim3(256), 0, s, g);
+  }
+}
+
+// Launch up to kGroupMax independent small products as one grid (gemm32_group_kernel).  Returns false --
+// nothing launched -- when a problem needs the stride-generic kernel or an epilogue the group kernel
+// does not carry, or when the products are big enough to deserve their own tuned launches.
+static bool gemm_launch_group(const GemmArgs* gs, const int* nb0s, int n, hipStream_t s) {
+  if (n < 2 || n > kGroupMax) return false;
+  GemmGroup grp{};
+  int vw = 4, total = 0;
+  for (int i = 0; i < n; ++i) {
+    const GemmArgs& g = gs[i];
+    if (g.bkscale || g.rowscale || g.addend) return false;
+    int v = 4;
+    const int fv = gemm_fast_variant(g, &v);
+    if (!fv) return false;
+    vw = v < vw ? v : vw;
+    grp.g[i] = g;
+    grp.ak[i] = ((fv - 1) >> 1) & 1;
+    grp.bj[i] = (fv - 1) & 1;
+    grp.gx[i] = (g.N + FN - 1) / FN;
+    grp.gy[i] = (g.M + FM - 1) / FM;
+    const long long cnt = (long long)grp.gx[i] * grp.gy[i] * nb0s[i] * g.nb1 * g.ksplit;
+    if (cnt > 1536) return false;                // a product this large keeps its own XCD-ordered launch
+    grp.first[i] = total;
+    total += (int)cnt;
+  }
+  if (total > 3072) return false;
+  for (int i = n; i <= kGroupMax; ++i) grp.first[i] = total;
+  grp.n = n;
+  const bool deep = total <= 2 * 256;
+  if (deep && vw == 4) hipLaunchKernelGGL((gemm32_group_kernel<32, 4>), dim3(total), dim3(256), 0, s, grp);
+  else if (vw == 4) hipLaunchKernelGGL((gemm32_group_kernel<16, 4>), dim3(total), dim3(256), 0, s, grp);
+  else if (deep) hipLaunchKernelGGL((gemm32_group_kernel<32, 2>), dim3(total), dim3(256), 0, s, grp);
+  else hipLaunchKernelGGL((gemm32_group_kernel<16, 2>), dim3(total), dim3(256), 0, s, grp);
+  return true;
+}
+
+// Several split-K reductions in one launch: problem p owns blocks [first[p], first[p+1]).
+struct ReduceGroup {
+  const float* part[kGroupMax];
+  float* out[kGroupMax];
+  long long n[kGroupMax];
+  int splits[kGroupMax];
+  int first[kGroupMax + 1];
+  int cnt;
+};
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroup rg) {
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < kGroupMax; ++i)
+    if (i < rg.cnt && (int)blockIdx.x >= rg.first[i]) p = i;
+  const float* __restrict__ part = rg.part[p];
+  float* __restrict__ out = rg.out[p];
+  const long long n = rg.n[p];
+  const int splits = rg.splits[p];
+  const long long stride = (long long)(rg.first[p + 1] - rg.first[p]) * 256;
+  for (long long e = (long long)(blockIdx.x - rg.first[p]) * 256 + threadIdx.x; e < n; e += stride) {
+    float s = 0.f;
+    for (int k0 = 0; k0 < splits; k0 += 8) {     // same order and batching as splitk_reduce_kernel
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(long long)min(k0 + u, splits - 1) * n + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (k0 + u < splits) ? v[u] : 0.f;
+    }
+    out[e] = s;
   }
 }
 
@@ -559,6 +668,35 @@ __global__ __launch_bounds__(256) void dbias_kernel(const float* __restrict__ to
   if (wave == 0 && ok) dbias[e] = s;
 }
 
+// Few outputs (sentence-vector geometry: per_n = M): the work IS the N-long dependent add chain of each
+// output, and rows of consecutive n share cache lines.  One wave, 64 loads in flight while the previous 64
+// values are added; no LDS, no barrier in the chain's way.
+__global__ __launch_bounds__(64) void dbias_chain_kernel(const float* __restrict__ top_diff, int N,
+                                                         int per_n, float* __restrict__ dbias) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= per_n) return;
+  float s = dbias[e];
+  constexpr int B = 64;
+  float cur[B], nxt[B];
+  const int full = N / B;
+  if (full > 0) {
+#pragma unroll
+    for (int u = 0; u < B; ++u) cur[u] = top_diff[(size_t)u * per_n + e];
+  }
+  for (int b = 0; b < full; ++b) {
+    if (b + 1 < full) {
+#pragma unroll
+      for (int u = 0; u < B; ++u) nxt[u] = top_diff[(size_t)((b + 1) * B + u) * per_n + e];
+    }
+#pragma unroll
+    for (int u = 0; u < B; ++u) s = cur[u] + s;
+#pragma unroll
+    for (int u = 0; u < B; ++u) cur[u] = nxt[u];
+  }
+  for (int n = full * B; n < N; ++n) s = top_diff[(size_t)n * per_n + e] + s;
+  dbias[e] = s;
+}
+
 static unsigned ew_blocks(long long n) {
   long long b = (n + 255) / 256;
   if (b > 4096) b = 4096;
@@ -585,7 +723,7 @@ static int pick_ksplit(int Mt, int Nt, int K, int* kchunk) {
 
 // ------------------------------ workspace layout ----------------------------
 struct BilinearWs {
-  size_t u_off, v_off, part_off, mpart_off, total;
+  size_t u_off, v_off, part_off, mpart_off, mpart2_off, total;
   int ksplit, kchunk;
 };
 static BilinearWs bilinear_ws(int N, int W1, int W2, int D, int M) {
@@ -596,8 +734,9 @@ static BilinearWs bilinear_ws(int N, int W1, int W2, int D, int M) {
   w.v_off = round_up(u * sizeof(float), 256);
   w.part_off = w.v_off + round_up(v * sizeof(float), 256);
   w.mpart_off = w.part_off + round_up((size_t)w.ksplit * M * D * D * sizeof(float), 256);
-  // per-measure partial products of dQ / dA (M > 1 only): [M][max(N*W1, N*W2)][D]
-  w.total = w.mpart_off + (M > 1 ? round_up((u > v ? u : v) * sizeof(float), 256) : 0);
+  // per-measure partial products of dQ and of dA (M > 1 only): [M][N*W1][D], [M][N*W2][D]
+  w.mpart2_off = w.mpart_off + (M > 1 ? round_up(u * sizeof(float), 256) : 0);
+  w.total = w.mpart2_off + (M > 1 ? round_up(v * sizeof(float), 256) : 0);
   return w;
 }
 size_t bilinear_workspace_bytes(int N, int W1, int W2, int D, int M) {
@@ -647,6 +786,16 @@ int bilinear_backward(int N, int W1, int W2, int D, int M, const float* q, const
   float* part = reinterpret_cast<float*>(base + lay.part_off);
   const long long R1 = (long long)N * W1, R2 = (long long)N * W2;
 
+  // dbias first: it depends on nothing the products write
+  if (bias_term) {
+    const int per_n = M * W1 * W2;
+    if (per_n <= 256)
+      hipLaunchKernelGGL(dbias_chain_kernel, dim3((per_n + 63) / 64), dim3(64), 0, s, top_diff, N, per_n,
+                         dbias);
+    else
+      hipLaunchKernelGGL(dbias_kernel, dim3((per_n + 63) / 64), dim3(256), 0, s, top_diff, N, per_n,
+                         dbias);
+  }
   // U_nm = dT_nm A_n  (W1 x D x W2) ;  V_nm = dT_nm^T Q_n  (W2 x D x W1)
   if (W1 == 1 && W2 == 1 && M == 1) {
     hipLaunchKernelGGL(rowscale_kernel, dim3(ew_blocks(R2 * D)), dim3(256), 0, s, a, top_diff, U,
@@ -654,57 +803,72 @@ int bilinear_backward(int N, int W1, int W2, int D, int M, const float* q, const
     hipLaunchKernelGGL(rowscale_kernel, dim3(ew_blocks(R1 * D)), dim3(256), 0, s, q, top_diff, V,
                        R1, D);
   } else {
-    GemmArgs gu = gemm_args(W1, D, W2, top_diff, W2, 1, a, D, 1, U, D);
-    gu.nb1 = M;
-    gu.a_b0 = (long long)M * W1 * W2; gu.a_b1 = (long long)W1 * W2;
-    gu.b_b0 = (long long)W2 * D; gu.b_b1 = 0;
-    gu.c_b0 = (long long)W1 * D; gu.c_b1 = R1 * D;
-    gemm_launch(gu, N, s);
-    GemmArgs gv = gemm_args(W2, D, W1, top_diff, 1, W2, q, D, 1, V, D);
-    gv.nb1 = M;
-    gv.a_b0 = (long long)M * W1 * W2; gv.a_b1 = (long long)W1 * W2;
-    gv.b_b0 = (long long)W1 * D; gv.b_b1 = 0;
-    gv.c_b0 = (long long)W2 * D; gv.c_b1 = R2 * D;
-    gemm_launch(gv, N, s);
+    GemmArgs guv[2];
+    guv[0] = gemm_args(W1, D, W2, top_diff, W2, 1, a, D, 1, U, D);
+    guv[0].nb1 = M;
+    guv[0].a_b0 = (long long)M * W1 * W2; guv[0].a_b1 = (long long)W1 * W2;
+    guv[0].b_b0 = (long long)W2 * D; guv[0].b_b1 = 0;
+    guv[0].c_b0 = (long long)W1 * D; guv[0].c_b1 = R1 * D;
+    guv[1] = gemm_args(W2, D, W1, top_diff, 1, W2, q, D, 1, V, D);
+    guv[1].nb1 = M;
+    guv[1].a_b0 = (long long)M * W1 * W2; guv[1].a_b1 = (long long)W1 * W2;
+    guv[1].b_b0 = (long long)W1 * D; guv[1].b_b1 = 0;
+    guv[1].c_b0 = (long long)W2 * D; guv[1].c_b1 = R2 * D;
+    const int nb[2] = {N, N};
+    if (!gemm_launch_group(guv, nb, 2, s)) {      // small batches: U and V in one launch
+      gemm_launch(guv[0], N, s);
+      gemm_launch(guv[1], N, s);
+    }
   }
-  // dQ_all = sum_m U_m W_m^T ; dA_all = sum_m V_m W_m   (:291-299; m = 0 overwrites,
-  // which also realises the unconditional zeroing of :176-177)
+  // dQ_all = sum_m U_m W_m^T ; dA_all = sum_m V_m W_m   (:291-299; m = 0 overwrites, which also realises
+  // the unconditional zeroing of :176-177) ; dW_m = Q_all^T U_m  (:286-289), K = N*W1 split across
+  // workgroups; W.diff is overwritten because the reference zeroes it first (:256).  The three products
+  // are independent: one grouped launch when they are small, then one grouped reduction.
+  GemmArgs g3[3];
+  const int one3[3] = {1, 1, 1};
+  const long long nW = (long long)M * D * D;
+  g3[2] = gemm_args(D, D, (int)R1, q, 1, D, U, D, 1, part, D);
+  g3[2].nb1 = M; g3[2].b_b1 = R1 * D; g3[2].c_b1 = (long long)D * D;
+  g3[2].ksplit = lay.ksplit; g3[2].kchunk = lay.kchunk; g3[2].c_ks = nW;
   if (M == 1) {
-    GemmArgs g1 = gemm_args((int)R1, D, D, U, D, 1, W, 1, D, dq, D);
-    gemm_launch(g1, 1, s);
-    GemmArgs g2 = gemm_args((int)R2, D, D, V, D, 1, W, D, 1, da, D);
-    gemm_launch(g2, 1, s);
+    g3[0] = gemm_args((int)R1, D, D, U, D, 1, W, 1, D, dq, D);
+    g3[1] = gemm_args((int)R2, D, D, V, D, 1, W, D, 1, da, D);
+    if (!gemm_launch_group(g3, one3, 3, s)) {
+      gemm_launch(g3[0], 1, s);
+      gemm_launch(g3[1], 1, s);
+      gemm_launch(g3[2], 1, s);
+    }
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks(nW)), dim3(256), 0, s, part, lay.ksplit, nW,
+                       dW, 0);
   } else {
-    // the M products of one operand run as ONE launch (M x the workgroups of a single product, which
-    // alone covers a fraction of the chip at the driver's sizes); their sum over m, ascending --
-    // the order the reference accumulates in -- is taken by splitk_reduce.
-    float* mpart = reinterpret_cast<float*>(base + lay.mpart_off);
-    GemmArgs g1 = gemm_args((int)R1, D, D, U, D, 1, W, 1, D, mpart, D);
-    g1.ksplit = M; g1.ks_stacked = 1; g1.a_ks = R1 * D; g1.b_ks = (long long)D * D; g1.c_ks = R1 * D;
-    gemm_launch(g1, 1, s);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks(R1 * D)), dim3(256), 0, s, mpart, M,
-                       R1 * D, dq, 0);
-    GemmArgs g2 = gemm_args((int)R2, D, D, V, D, 1, W, D, 1, mpart, D);
-    g2.ksplit = M; g2.ks_stacked = 1; g2.a_ks = R2 * D; g2.b_ks = (long long)D * D; g2.c_ks = R2 * D;
-    gemm_launch(g2, 1, s);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks(R2 * D)), dim3(256), 0, s, mpart, M,
-                       R2 * D, da, 0);
-  }
-  // dW_m = Q_all^T U_m  (:286-289), K = N*W1 split across workgroups; W.diff is
-  // overwritten because the reference zeroes it first (:256).
-  {
-    GemmArgs g = gemm_args(D, D, (int)R1, q, 1, D, U, D, 1, part, D);
-    g.nb1 = M; g.b_b1 = R1 * D; g.c_b1 = (long long)D * D;
-    g.ksplit = lay.ksplit; g.kchunk = lay.kchunk; g.c_ks = (long long)M * D * D;
-    gemm_launch(g, 1, s);
-    const long long n = (long long)M * D * D;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, part,
-                       lay.ksplit, n, dW, 0);
-  }
-  if (bias_term) {
-    const int per_n = M * W1 * W2;
-    hipLaunchKernelGGL(dbias_kernel, dim3((per_n + 63) / 64), dim3(256), 0, s, top_diff, N,
-                       per_n, dbias);
+    // the M products of one operand run as ONE "stacked" split-K product (chunk m = measure m: M x the
+    // workgroups of a single product, which alone covers a fraction of the chip at the driver's sizes);
+    // their sum over m, ascending -- the order the reference accumulates in -- is taken by the reduction.
+    float* mq = reinterpret_cast<float*>(base + lay.mpart_off);
+    float* ma = reinterpret_cast<float*>(base + lay.mpart2_off);
+    g3[0] = gemm_args((int)R1, D, D, U, D, 1, W, 1, D, mq, D);
+    g3[0].ksplit = M; g3[0].ks_stacked = 1; g3[0].a_ks = R1 * D; g3[0].b_ks = (long long)D * D; g3[0].c_ks = R1 * D;
+    g3[1] = gemm_args((int)R2, D, D, V, D, 1, W, D, 1, ma, D);
+    g3[1].ksplit = M; g3[1].ks_stacked = 1; g3[1].a_ks = R2 * D; g3[1].b_ks = (long long)D * D; g3[1].c_ks = R2 * D;
+    if (!gemm_launch_group(g3, one3, 3, s)) {
+      gemm_launch(g3[0], 1, s);
+      gemm_launch(g3[1], 1, s);
+      gemm_launch(g3[2], 1, s);
+    }
+    ReduceGroup rg{};
+    const float* parts[3] = {mq, ma, part};
+    float* outs[3] = {dq, da, dW};
+    const long long ns[3] = {R1 * D, R2 * D, nW};
+    const int sp[3] = {M, M, lay.ksplit};
+    int first = 0;
+    for (int i = 0; i < 3; ++i) {
+      rg.part[i] = parts[i]; rg.out[i] = outs[i]; rg.n[i] = ns[i]; rg.splits[i] = sp[i];
+      rg.first[i] = first;
+      first += (int)ew_blocks(ns[i]);
+    }
+    rg.first[3] = first;
+    rg.cnt = 3;
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(first), dim3(256), 0, s, rg);
   }
   return launch_status();
 }
