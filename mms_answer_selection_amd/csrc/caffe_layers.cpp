@@ -1109,7 +1109,8 @@ std::vector<int> shape_vec(const int* shape, int n) { return std::vector<int>(sh
 extern "C" {
 
 mms_blob_t* mms_blob_create(const int* shape, int num_axes) {
-  mms_blob_t* h = new mms_blob{new caffe::Blob<float>(shape_vec(shape, num_axes)), nullptr, true};
+  // no axes = the default constructor (count 0, nothing allocated: blob.hpp:26-27), as `new Blob<Dtype>()`
+  mms_blob_t* h = new mms_blob{num_axes > 0 ? new caffe::Blob<float>(shape_vec(shape, num_axes)) : new caffe::Blob<float>(), nullptr, true};
   return h;
 }
 void mms_blob_destroy(mms_blob_t* b) {
