@@ -554,6 +554,18 @@ def other_configs(torch, capi):
         out[name] = {"us_per_step": us, "pairs_per_s": n / (us * 1e-6), "GBps_algorithmic": b / us / 1e3,
                      "bound": "fp32 VALU (3 flop per (j,k,d), d-ordered sums)"}
         del qg, ag, tg
+    # cfg 4 in the mode the reference's network_v4 scores with: SimCross bilinear, M = 4, bias (forward only)
+    n = 1517
+    qg, ag = rnd(n, 40, 50), rnd(n, 40, 50)
+    Wb = torch.rand(4, 50, 50, device="cuda", generator=g) * 0.16 - 0.08
+    bb = torch.zeros(4, 40, 40, device="cuda")
+    tb = torch.empty(n, 4, 40, 40, device="cuda")
+    us = _graph_time(torch, lambda: capi.simcross_forward(2, qg, ag, tb, W=Wb, bias=bb, ws=ws))
+    fl = 2.0 * n * 4 * 40 * 50 * (50 + 40)
+    out["cfg4_scoring_bilinear_M4_1517x40x40x50_forward"] = {
+        "us_per_step": us, "pairs_per_s": n / (us * 1e-6), "TFLOPs": fl / us / 1e6,
+        "note": "one fused launch per step (Q_n W_m kept in LDS); 89 us as two batched GEMMs"}
+    del qg, ag, Wb, bb, tb
     # the same scores from WORD IDS: Embed (50-d table, 20,000 words) then SimCross, and the fused call
     n, K = 1517, 20000
     tab = rnd(K, 50)

@@ -743,11 +743,164 @@ size_t bilinear_workspace_bytes(int N, int W1, int W2, int D, int M) {
   return bilinear_ws(N, W1, W2, D, M).total;
 }
 
+// LDS writes of this wave visible to its own later reads (no other wave touches the slice)
+__device__ __forceinline__ void wave_lds_sync_local() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- fused forward for word grids (the driver's 40 x 40 x Dw geometry) ---------------------------
+// One workgroup per pair n: T[n,m] = (Q_n W_m) A_n^T + bias_m for every measure m, with Q_n W_m kept in
+// LDS -- the (M, N*W1, D) intermediate of the two-GEMM formulation (written to and read back from HBM:
+// 2 x 48 MB at the 1517-candidate test split) never exists, and the forward is ONE launch.
+//   * q_n and a_n are staged once as zero-padded images, row stride 68 floats (rows 4 banks apart: the
+//     16 rows x 4 k of an MFMA operand read hit 64 distinct banks);
+//   * work items (measure m, 16-row tile of Q) are dealt to the four waves.  An item runs
+//     stage 1  tmp (16 x D)  = Q rows x W_m : ceil(D/16) accumulators, B operand W_m[k][j] read straight
+//              from global memory (M*D*D floats: L1/L2-resident), one 4-byte load per MFMA;
+//     stage 2  T   (16 x W2) = tmp x A_n^T  : tmp goes through the wave's own LDS slice to become an A
+//              operand (k-major per lane), B operand from the a image;
+//   * v_mfma_f32_16x16x4_f32: W = 40 fills 40/48 of the tiles (32x32 tiles: 40/64).
+// Eligible for W1, W2 <= 48 and D <= 64; anything else takes the two batched GEMMs below.
+constexpr int PF_LS = 68, PF_ROWS = 48, PF_TD = 4;
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int KS>                                  // k steps of 4: 13 covers D <= 52 (the driver's 50), 16 D <= 64
+__global__ __launch_bounds__(256) void bilinear_pair_fwd_kernel(
+    int N, int W1, int W2, int D, int M, const float* __restrict__ q, const float* __restrict__ a,
+    const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ top) {
+  __shared__ float qs[PF_ROWS * PF_LS];
+  __shared__ float as[PF_ROWS * PF_LS];
+  __shared__ float ts[4][16 * PF_LS];
+  const int n = blockIdx.x;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const float* qn = q + (size_t)n * W1 * D;
+  const float* an = a + (size_t)n * W2 * D;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ti_n = (W1 + 15) / 16;
+  // Items are dealt in contiguous runs (m-major), so a wave mostly stays on one measure and keeps that
+  // measure's B operands -- W_m[k][j] for its lane, all k steps -- in registers: they are fetched once,
+  // all loads in flight together (a load per MFMA inside the k loop costs a memory round trip per step).
+  const int items = M * ti_n, per = (items + 3) / 4;
+  float wf[KS][PF_TD];
+  auto fetch_w = [&](int m) {
+    const float* Wm = W + (size_t)m * D * D;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + lk;
+#pragma unroll
+      for (int d = 0; d < PF_TD; ++d) wf[ks][d] = Wm[(size_t)min(k, D - 1) * D + min(16 * d + li, D - 1)];
+    }
+  };
+  auto mask_w = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int d = 0; d < PF_TD; ++d)
+        if (!(4 * ks + lk < D && 16 * d + li < D)) wf[ks][d] = 0.f;
+  };
+  int have_m = -1;
+  if (wave * per < items) {                        // the first measure's operands: in flight behind the staging
+    have_m = (wave * per) / ti_n;
+    fetch_w(have_m);
+  }
+  // zero-padded images: every load issued (clamped, unconditional) before the first LDS write
+  constexpr int NE = (PF_ROWS * PF_LS + 255) / 256;
+  float vq[NE], va[NE];
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int e = 256 * u + t;
+    const int r = e / PF_LS, c = e - r * PF_LS;
+    vq[u] = qn[(size_t)min(r, W1 - 1) * D + min(c, D - 1)];
+    va[u] = an[(size_t)min(r, W2 - 1) * D + min(c, D - 1)];
+  }
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int e = 256 * u + t;
+    const int r = e / PF_LS, c = e - r * PF_LS;
+    if (e < PF_ROWS * PF_LS) {
+      qs[e] = (r < W1 && c < D) ? vq[u] : 0.f;
+      as[e] = (r < W2 && c < D) ? va[u] : 0.f;
+    }
+  }
+  __syncthreads();
+  if (have_m >= 0) mask_w();
+  float* tw = ts[wave];
+  for (int item = wave * per; item < min(items, (wave + 1) * per); ++item) {
+    const int m = item / ti_n, ti = item - m * ti_n;
+    if (m != have_m) {
+      fetch_w(m);
+      mask_w();
+      have_m = m;
+    }
+    // stage 1: tmp[16 x D] = Q[16 rows of tile ti] . W_m
+    v4f acc1[PF_TD];
+#pragma unroll
+    for (int d = 0; d < PF_TD; ++d) acc1[d] = (v4f){0.f, 0.f, 0.f, 0.f};
+    // padded tiles are computed too (their operands are zero): no branch between MFMAs
+    float a1[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a1[ks] = qs[(16 * ti + li) * PF_LS + 4 * ks + lk];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int d = 0; d < PF_TD; ++d)
+        acc1[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], wf[ks][d], acc1[d], 0, 0, 0);
+    }
+    // C layout: col = lane & 15, row = 4 * (lane >> 4) + reg  ->  the wave's LDS slice, row-major
+#pragma unroll
+    for (int d = 0; d < PF_TD; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tw[(4 * lk + r) * PF_LS + 16 * d + li] = acc1[d][r];
+    wave_lds_sync_local();
+    // stage 2: T[16 x W2] = tmp . A_n^T   (B[k][j] = a[j][k])
+    v4f acc2[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc2[c] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + lk;
+      const float av = tw[li * PF_LS + k];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        acc2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, as[(16 * c + li) * PF_LS + k], acc2[c], 0, 0, 0);
+    }
+    wave_lds_sync_local();                         // tw is rewritten by this wave's next item
+    float* tn = top + ((size_t)n * M + m) * W1 * W2;
+    const float* bm = bias ? bias + (size_t)m * W1 * W2 : nullptr;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int col = 16 * c + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti + 4 * lk + r;
+        if (row < W1 && col < W2) {
+          float v = acc2[c][r];
+          if (bm) v = bm[row * W2 + col] + v;      // the addend form of the GEMM epilogue (:156-158)
+          tn[row * W2 + col] = v;
+        }
+      }
+    }
+  }
+}
+
 int bilinear_forward(int N, int W1, int W2, int D, int M, const float* q, const float* a,
                      const float* W, const float* bias, float* top, void* ws, size_t ws_bytes,
                      hipStream_t s) {
   const BilinearWs lay = bilinear_ws(N, W1, W2, D, M);
   if (!ws || ws_bytes < lay.total) return MMS_ERR_WORKSPACE;
+  // large batches only (evaluation: the 1517 TREC-QA test candidates, 89 -> 59 us): at the training batch of
+  // 50 pairs both forms sit at the launch floor and the two small GEMMs are marginally quicker
+  if (W1 <= PF_ROWS && W2 <= PF_ROWS && D <= 16 * PF_TD && W1 * W2 > 1 && N >= 512) {
+    if (D <= 52)
+      hipLaunchKernelGGL(bilinear_pair_fwd_kernel<13>, dim3(N), dim3(256), 0, s, N, W1, W2, D, M, q, a, W,
+                         bias, top);
+    else
+      hipLaunchKernelGGL(bilinear_pair_fwd_kernel<16>, dim3(N), dim3(256), 0, s, N, W1, W2, D, M, q, a, W,
+                         bias, top);
+    return launch_status();
+  }
   float* tmp = reinterpret_cast<float*>(static_cast<char*>(ws) + lay.u_off);
   const long long R = (long long)N * W1;
   // tmp[m] = Q_all W_m   (:148-149, batched over all pairs)

@@ -371,7 +371,9 @@ def test_bilinear_shape_fuzz(oracle, hiplib):
     (stacked split-K over m), W1 != W2, batch sizes on both sides of the deep-k-tile threshold."""
     from mms_answer_selection_amd import capi
     r = rng(77)
-    shapes = [(50, 40, 40, 50, 4), (32, 40, 40, 300, 4), (70, 24, 40, 50, 3), (600, 1, 1, 50, 2)]
+    shapes = [(50, 40, 40, 50, 4), (32, 40, 40, 300, 4), (70, 24, 40, 50, 3), (600, 1, 1, 50, 2),
+              # >= 512 pairs of word grids: the fused one-launch forward (Q_n W_m kept in LDS)
+              (520, 40, 40, 50, 4), (513, 17, 33, 64, 2), (600, 48, 48, 52, 1), (512, 5, 7, 9, 3)]
     for _ in range(10):
         shapes.append((int(r.integers(1, 40)), int(r.integers(1, 45)), int(r.integers(1, 45)),
                        int(r.choice([6, 10, 12, 18, 20, 33, 50, 64, 100])), int(r.integers(1, 5))))
