@@ -379,39 +379,52 @@ __global__ __launch_bounds__(64 * WPB) void euclid_pair32_kernel(
 // MI355X-side storage format, not a change of the layer's numerics.
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-template <int NIT, bool BWD>
+// RW pairs per wave (64 / RW lanes each).  At D = 1024 the ordered chain is 55 % of the kernel
+// (tools/f16abl.sh: 18.6 us with, 8.3 us without it at 8192 pairs): two pairs per wave would halve its
+// VALU issue cost per pair, but the narrower speculation windows (+-12 / +-15 ulp instead of +-25 / +-36)
+// miss too often there (see simcross_euclid_rows_f16); a miss re-walks one segment exactly, so results
+// never change, only time.
+template <int NIT, int RW, bool BWD>
 __global__ __launch_bounds__(256) void euclid_rows_wave_f16_kernel(
     const _Float16* __restrict__ q, const _Float16* __restrict__ a,
     const float* __restrict__ top_diff, float* __restrict__ top_out,
     _Float16* __restrict__ dq, _Float16* __restrict__ da, int N, int D8) {
-  constexpr int LPR = 64;
-  extern __shared__ float4 lds4[];               // [4 waves] one image each (euclid_math.h)
+  constexpr int LPR = 64 / RW;
+  extern __shared__ float4 lds4[];               // [4 waves][RW images] (euclid_math.h)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= N) return;
+  const int row0 = (blockIdx.x * 4 + wave) * RW;
+  if (row0 >= N) return;
+  const int rows = min(RW, N - row0);
+  const int n8 = rows * D8;
   const int D4 = 2 * D8;
-  const size_t base8 = (size_t)row * D8;
+  const size_t base8 = (size_t)row0 * D8;
   const half8* q8 = reinterpret_cast<const half8*>(q) + base8;
   const half8* a8 = reinterpret_cast<const half8*>(a) + base8;
   const int st4 = spec_stride4(D4), h4 = spec_h4(D4);
-  float4* sq4 = lds4 + (size_t)wave * st4;
+  float4* sq4 = lds4 + (size_t)wave * RW * st4;
 
   half8 x[NIT], y[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = lane + 64 * it;
-    const int ii = i < D8 ? i : 0;
+    const int ii = i < n8 ? i : 0;
     x[it] = q8[ii];
     y[it] = a8[ii];
   }
+  const int grp = lane / LPR, j = lane % LPR;
+  const int grow = min(grp, rows - 1);           // a missing 2nd pair mirrors the 1st (results unused)
   float g = 0.f;
-  if (BWD) g = top_diff[row];
+  if (BWD) g = top_diff[row0 + grow];
 
   float4 df[2 * NIT];
-  float pred1 = 0.f, pred2 = 0.f;
+  float2v pred[RW];                              // per pair: (pred1, pred2) partial sums
+#pragma unroll
+  for (int r = 0; r < RW; ++r) pred[r] = (float2v){0.f, 0.f};
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = lane + 64 * it;
+    const bool r1 = (RW == 2) && (i >= D8);
+    const int ir = r1 ? i - D8 : i;              // half8 index inside its pair
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       float4 d;
@@ -422,30 +435,55 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_f16_kernel(
       df[2 * it + hh] = d;
       float4 s;
       s.x = d.x * d.x; s.y = d.y * d.y; s.z = d.z * d.z; s.w = d.w * d.w;
-      const int i4 = 2 * i + hh;
-      if (i < D8) sq4[i4] = s;
-      const float s4 = (i < D8) ? (s.x + s.y) + (s.z + s.w) : 0.f;
-      pred1 += (i4 < h4) ? s4 : 0.f;
-      pred2 += (i4 < 2 * h4) ? s4 : 0.f;
+      const int i4 = 2 * ir + hh;                // float4 index inside the pair's image
+      if (i < n8) sq4[(r1 ? st4 : 0) + i4] = s;
+      const float s4 = (i < n8) ? (s.x + s.y) + (s.z + s.w) : 0.f;
+      float2v c;
+      c.x = (i4 < h4) ? s4 : 0.f;
+      c.y = (i4 < 2 * h4) ? s4 : 0.f;
+      const float2v z2 = {0.f, 0.f};
+      pred[0] += r1 ? z2 : c;
+      if (RW == 2) pred[RW - 1] += r1 ? c : z2;
     }
   }
   const int npad = st4 - D4;
-  if (lane < npad) sq4[D4 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-  pred1 = wave_sum(pred1);
-  pred2 = wave_sum(pred2);
+  if (lane < RW * npad) sq4[(lane / npad) * st4 + D4 + (lane % npad)] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float my1 = 0.f, my2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const float p1 = wave_sum(pred[r].x), p2 = wave_sum(pred[r].y);
+    if (r == grow) { my1 = p1; my2 = p2; }
+  }
   wave_lds_sync();
-  const float dist = chain_sum_speculative<LPR>(sq4, D4, pred1, pred2, lane, 0);
+#if defined(MMS_F16ABL) && MMS_F16ABL == 1     // dev-only timing ablation (tools/f16bench.hip): no chain
+  const float dist = my2;
+#else
+  const float dist = chain_sum_speculative<LPR>(sq4 + grow * st4, D4, my1, my2, j, grp * LPR);
+#endif
   const float T = 1.0f / (1.0f + sqrtf(dist));
-  if (lane == 0) top_out[row] = T;
+  if (j == 0 && grp < rows) top_out[row0 + grp] = T;
   if (!BWD) return;
 
-  const EuclidCoef k = euclid_coef(T, g);
+  const EuclidCoef mine = euclid_coef(T, g);
+  EuclidCoef kr[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {                 // lane r*LPR is a compile-time lane: v_readlane
+    kr[r].c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c), r * LPR));
+    const long long dn = __double_as_longlong(mine.den), rc = __double_as_longlong(mine.rcp);
+    const unsigned dlo = __builtin_amdgcn_readlane((int)(unsigned)dn, r * LPR);
+    const unsigned dhi = __builtin_amdgcn_readlane((int)(unsigned)(dn >> 32), r * LPR);
+    const unsigned rlo = __builtin_amdgcn_readlane((int)(unsigned)rc, r * LPR);
+    const unsigned rhi = __builtin_amdgcn_readlane((int)(unsigned)(rc >> 32), r * LPR);
+    kr[r].den = __longlong_as_double((long long)(((unsigned long long)dhi << 32) | dlo));
+    kr[r].rcp = __longlong_as_double((long long)(((unsigned long long)rhi << 32) | rlo));
+  }
   half8* dq8 = reinterpret_cast<half8*>(dq) + base8;
   half8* da8 = reinterpret_cast<half8*>(da) + base8;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = lane + 64 * it;
-    if (i >= D8) break;
+    if (i >= n8) break;
+    const EuclidCoef& k = (RW == 2 && i >= D8) ? kr[RW - 1] : kr[0];
     half8 o0, o1;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
@@ -455,8 +493,13 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_f16_kernel(
       o1[4 * hh + 0] = (_Float16)(0.f + (-t.x)); o1[4 * hh + 1] = (_Float16)(0.f + (-t.y));
       o1[4 * hh + 2] = (_Float16)(0.f + (-t.z)); o1[4 * hh + 3] = (_Float16)(0.f + (-t.w));
     }
-    stream_store_vec(dq8 + i, o0);
-    stream_store_vec(da8 + i, o1);
+#if defined(MMS_F16ABL) && MMS_F16ABL == 2     // dev-only timing ablation: no stores
+    if (T == 12345.0f)
+#endif
+    {
+      stream_store_vec(dq8 + i, o0);
+      stream_store_vec(da8 + i, o1);
+    }
   }
 }
 
@@ -466,24 +509,43 @@ int simcross_euclid_rows_f16(int N, int D, const void* q, const void* a, const f
   if (D % 8 != 0 || D > 2048 || !aligned16(q) || !aligned16(a) || (bwd && (!aligned16(dq) || !aligned16(da))))
     return MMS_ERR_UNSUPPORTED;
   const int D8 = D / 8;
-  const int nit = (D8 + 63) / 64;
-  const unsigned grid = (unsigned)((N + 3) / 4);
-  const size_t lds = (size_t)4 * 3 * ((2 * D8 + 2) / 3) * sizeof(float4);
+  // Two pairs per wave (32 candidate lanes each) only while the narrower windows hold: at D = 1024 the
+  // ordered fp32 sum of a 344-term segment strays sigma ~ 6 ulp from its tree-sum prediction, the +-12 / +-15
+  // windows of 32 lanes missed on 3.4 % of pairs (tools/f16abl.sh) and the exact re-walks ate the gain at
+  // cfg 5's shard size (19.5 vs 18.6 us; 125 vs 149 us at 65536 pairs).  Same limit as the fp32 kernels.
+  const int rw = D <= 400 ? 2 : 1;
+  const int nit = (rw * D8 + 63) / 64;
+  const unsigned grid = (unsigned)((N + 4 * rw - 1) / (4 * rw));
+  const size_t lds = (size_t)4 * rw * 3 * ((2 * D8 + 2) / 3) * sizeof(float4);
   const _Float16* qh = static_cast<const _Float16*>(q);
   const _Float16* ah = static_cast<const _Float16*>(a);
   _Float16* dqh = static_cast<_Float16*>(dq);
   _Float16* dah = static_cast<_Float16*>(da);
-#define MMS_F16_CASE(n)                                                                          \
-  case n:                                                                                        \
-    if (bwd)                                                                                     \
-      hipLaunchKernelGGL((euclid_rows_wave_f16_kernel<n, true>), dim3(grid), dim3(256), lds, s,  \
-                         qh, ah, top_diff, top, dqh, dah, N, D8);                                \
-    else                                                                                         \
-      hipLaunchKernelGGL((euclid_rows_wave_f16_kernel<n, false>), dim3(grid), dim3(256), lds, s, \
-                         qh, ah, top_diff, top, dqh, dah, N, D8);                                \
-    break;
-  switch (nit) { MMS_F16_CASE(1) MMS_F16_CASE(2) MMS_F16_CASE(3) MMS_F16_CASE(4) }
-#undef MMS_F16_CASE
+#define MMS_F16_LAUNCH(n, r)                                                                          \
+  do {                                                                                                \
+    if (bwd)                                                                                          \
+      hipLaunchKernelGGL((euclid_rows_wave_f16_kernel<n, r, true>), dim3(grid), dim3(256), lds, s,    \
+                         qh, ah, top_diff, top, dqh, dah, N, D8);                                     \
+    else                                                                                              \
+      hipLaunchKernelGGL((euclid_rows_wave_f16_kernel<n, r, false>), dim3(grid), dim3(256), lds, s,   \
+                         qh, ah, top_diff, top, dqh, dah, N, D8);                                     \
+  } while (0)
+  if (rw == 2) {
+    switch (nit) {
+      case 1: MMS_F16_LAUNCH(1, 2); break;
+      case 2: MMS_F16_LAUNCH(2, 2); break;
+      case 3: MMS_F16_LAUNCH(3, 2); break;
+      default: MMS_F16_LAUNCH(4, 2); break;
+    }
+  } else {
+    switch (nit) {
+      case 1: MMS_F16_LAUNCH(1, 1); break;
+      case 2: MMS_F16_LAUNCH(2, 1); break;
+      case 3: MMS_F16_LAUNCH(3, 1); break;
+      default: MMS_F16_LAUNCH(4, 1); break;
+    }
+  }
+#undef MMS_F16_LAUNCH
   return launch_status();
 }
 
