@@ -834,6 +834,17 @@ __global__ __launch_bounds__(256) void bilinear_pair_fwd_kernel(
       mask_w();
       have_m = m;
     }
+    // this item's bias values: requested now, used after the two stages (a load in the epilogue would
+    // expose a memory round trip per item)
+    const float* bm = bias ? bias + (size_t)m * W1 * W2 : nullptr;
+    float bv[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = min(16 * ti + 4 * lk + r, W1 - 1), col = min(16 * c + li, W2 - 1);
+        bv[c][r] = bm ? bm[row * W2 + col] : 0.f;
+      }
     // stage 1: tmp[16 x D] = Q[16 rows of tile ti] . W_m
     v4f acc1[PF_TD];
 #pragma unroll
@@ -868,7 +879,6 @@ __global__ __launch_bounds__(256) void bilinear_pair_fwd_kernel(
     }
     wave_lds_sync_local();                         // tw is rewritten by this wave's next item
     float* tn = top + ((size_t)n * M + m) * W1 * W2;
-    const float* bm = bias ? bias + (size_t)m * W1 * W2 : nullptr;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int col = 16 * c + li;
@@ -877,7 +887,7 @@ __global__ __launch_bounds__(256) void bilinear_pair_fwd_kernel(
         const int row = 16 * ti + 4 * lk + r;
         if (row < W1 && col < W2) {
           float v = acc2[c][r];
-          if (bm) v = bm[row * W2 + col] + v;      // the addend form of the GEMM epilogue (:156-158)
+          if (bm) v = bv[c][r] + v;                // the addend form of the GEMM epilogue (:156-158)
           tn[row * W2 + col] = v;
         }
       }
