@@ -398,6 +398,20 @@ def test_bilinear_shape_fuzz(oracle, hiplib):
         assert_bitexact(host(gb), db_ref, what + "dbias")
 
 
+def test_bilinear_fused_forward_without_bias_and_ragged_tiles(oracle, hiplib):
+    """The one-launch forward for large batches of word grids (>= 512 pairs): no bias, tile remainders in
+    every dimension, and the largest geometry it accepts."""
+    from mms_answer_selection_amd import capi
+    r = rng(91)
+    for (N, W1, W2, D, M) in [(512, 8, 8, 16, 1), (515, 17, 3, 5, 2), (512, 48, 48, 64, 1), (640, 1, 9, 7, 5)]:
+        q, a = qa(r, N, W1, W2, D)
+        W = r.uniform(-0.1, 0.1, (M, D, D)).astype(np.float32)
+        top_ref, _, _ = oracle.simcross_forward(2, q, a, W, None)
+        top = nan_like(top_ref.shape)
+        capi.simcross_forward(2, dev(q), dev(a), top, W=dev(W), bias=None)
+        assert_close(host(top), top_ref, TOL, "top %s" % ((N, W1, W2, D, M),))
+
+
 # --------------------------------------------------------------------------- #
 # SimMatrix: 1e-5
 # --------------------------------------------------------------------------- #
