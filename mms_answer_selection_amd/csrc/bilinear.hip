@@ -704,18 +704,27 @@ static unsigned ew_blocks(long long n) {
   return (unsigned)b;
 }
 
-static int pick_ksplit(int Mt, int Nt, int K, int* kchunk) {
-  const long long tiles = (long long)((Mt + FM - 1) / FM) * ((Nt + FN - 1) / FN);
-  long long want = (768 + tiles - 1) / tiles;   // aim for ~3 workgroups per CU
-  long long maxs = (K + 63) / 64;               // at least 64 of K (two deep k-tiles) per split
-  if (want > maxs) want = maxs;
-  if (want < 1) want = 1;
-  if (want > 256) want = 256;
-  if (want >= 8) {                              // tiles x splits divisible by 8: the XCD-aware order applies
-    const long long w8 = (want + 7) / 8 * 8;
-    want = w8 <= maxs ? w8 : (maxs >= 8 ? maxs / 8 * 8 : want);
+// Split count for a product with a long K (the dW products: K = pairs).  Workgroups = tiles x batch x
+// splits; the chip takes them 256 x (workgroups per CU) at a time, so the count should (a) reach ~3 per CU
+// and (b) nearly FILL its last round: 25 tiles x 32 splits = 800 is 3.1 per CU -- a fourth round for 12 %
+// of the CUs, 78 % efficient -- while 25 x 40 = 1000 fills 97.6 % of four rounds (cfg 3's dW product:
+// 52 -> 44 us).  Splits of 8 or more come in multiples of 8 so that the XCD-aware order applies.
+static int pick_ksplit(int Mt, int Nt, int K, int* kchunk, int batch = 1) {
+  const long long tiles = (long long)((Mt + FM - 1) / FM) * ((Nt + FN - 1) / FN) * (batch > 0 ? batch : 1);
+  const long long maxs = (K + 63) / 64;           // at least 64 of K (two deep k-tiles) per split
+  long long best = 1;
+  double best_score = -1.0;
+  for (long long sp = 1; sp <= maxs && sp <= 256; ++sp) {
+    if (sp >= 8 && (sp & 7)) continue;
+    const long long x = tiles * sp;
+    if (x > 1280 && sp > 1) break;
+    const double rounds = (double)((x + 255) / 256);
+    const double eff = (double)x / 256.0 / rounds;              // how full the last round is
+    const double fill = x >= 768 ? 1.0 : (double)x / 768.0;     // ~3 workgroups per CU hide latency
+    const double score = eff * fill;
+    if (score > best_score + 1e-9) { best_score = score; best = sp; }
   }
-  int chunk = (int)((K + want - 1) / want);
+  int chunk = (int)((K + best - 1) / best);
   chunk = (chunk + 31) / 32 * 32;               // a multiple of either k-tile depth (16, 32)
   *kchunk = chunk;
   return (K + chunk - 1) / chunk;
@@ -729,7 +738,7 @@ struct BilinearWs {
 static BilinearWs bilinear_ws(int N, int W1, int W2, int D, int M) {
   BilinearWs w{};
   const size_t u = (size_t)M * N * W1 * D, v = (size_t)M * N * W2 * D;
-  w.ksplit = pick_ksplit(D, D, N * W1, &w.kchunk);
+  w.ksplit = pick_ksplit(D, D, N * W1, &w.kchunk, M);
   w.u_off = 0;
   w.v_off = round_up(u * sizeof(float), 256);
   w.part_off = w.v_off + round_up(v * sizeof(float), 256);
