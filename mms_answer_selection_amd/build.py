@@ -44,16 +44,37 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, f) for f in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, f) for f in HIP_HEADERS] + [
-        os.path.join(ROOT, "include", "mms.h"), os.path.abspath(__file__)]
-    if not force and not _stale(LIB, deps):
-        return LIB
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC] + srcs + ["-o", LIB]
+def _compile_one(args):
+    cmd, verbose = args
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+
+
+def build_hip(force=False, verbose=False):
+    """One object per .hip source (compiled in parallel, rebuilt only when stale), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    hdrs = [os.path.join(CSRC, f) for f in HIP_HEADERS] + [
+        os.path.join(ROOT, "include", "mms.h"), os.path.abspath(__file__)]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs, objs = [], []
+    for f in HIP_SOURCES:
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(objdir, f.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append(([_hipcc()] + cflags + ["-c", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+                                                src, "-o", obj], verbose))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as ex:
+            list(ex.map(_compile_one, jobs))
+    if jobs or force or _stale(LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB
 
 
