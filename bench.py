@@ -8,18 +8,28 @@ T (4096,1,1,1), forward + backward with a given top_diff, per GPU.
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one forward+backward pass over one 4096-pair batch through the C
-ABI (mms_simcross_forward_backward_f32: one launch).  Inputs are resident in
-HBM before the timed region.  To keep the numbers HBM-bound rather than
-Infinity-Cache-bound, the steps walk a ring of RING distinct batches
-(RING x 19.7 MB > 1 GiB >> 256 MiB of L3); `--warm` re-uses one batch instead.
-Steps are captured GROUP at a time into hipGraphs (launch-bound inner loop) and
-replayed; N > 1 shards pairs over ranks (weak scaling: 4096 pairs per GPU) and
-all-gathers the per-pair scores of each GROUP of steps with one RCCL call on a
-side stream, overlapped with the next group's compute.
+A "step" is one forward + one backward pass over one 4096-pair batch through the C ABI.  The
+default `--path layers` issues what a Caffe host can issue through the Layer API: one Forward
+launch (mms_simcross_forward_f32), then one Backward launch (mms_simcross_backward_f32) --
+Net::ForwardFromTo / BackwardFromTo (net.cpp:535-546, 581-591) and `caffe time`
+(tools/caffe.cpp:349-361) run all forwards, then all backwards, so no reference caller can hand
+top_diff to the forward.  `--path fused` (one launch for both, mms_simcross_forward_backward_f32)
+is a labelled variant for hosts that do know top_diff up front.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
-and `cpu_baseline` objects added.
+Protocol (SURVEY.md 8d, tools/caffe.cpp:318-385): inputs resident in HBM; W untimed warm-up steps;
+then the K-step region is timed REPEATS (5) times, each repeat bracketed by barrier +
+torch.cuda.synchronize() on both sides and by two HIP events on the launch stream; ONE clock -- the
+events, max over ranks -- gives `value`, `ms_per_step` and `roofline`; the MEDIAN repeat is
+reported (all repeats are in `config.repeats_ms_per_step`).  Steps walk a ring of RING distinct
+batches (RING x 19.7 MB > 1 GiB >> 256 MiB of Infinity Cache) continuing where the warm-up stopped,
+and the caches are flushed (a 512 MiB fill) before the warm-up, so every timed step reads its q and
+a from HBM ("cold"); `--warm` re-uses one batch instead.  Steps are captured into hipGraphs of up
+to GROUP steps (launch-bound inner loop).  N > 1 shards pairs over ranks (weak scaling: 4096 pairs
+per GPU) and all-gathers the per-pair scores of each GROUP of steps with one RCCL call on a side
+stream, overlapped with the next group's compute; `--workload cfg5` / `cfg4` are the
+strong-scaling legs of the two BASELINE configurations that are multi-GPU by definition.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
 import argparse
 import json
@@ -38,6 +48,7 @@ B_BWD = S * (2 * N_PAIRS * 2 * DIM + 2 * N_PAIRS)      # 19,693,568
 B_UNFUSED = B_FWD + B_BWD                              # 29,540,352  (7,212 B/pair)
 B_FUSED = S * (2 * N_PAIRS * 2 * DIM + 2 * N_PAIRS)    # q,a read once; dq,da written once; dT in, T out
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+REPEATS = 5
 
 
 def parse():
@@ -48,9 +59,15 @@ def parse():
     p.add_argument("--group", type=int, default=64, help="steps per hipGraph / all-gather bucket")
     p.add_argument("--ring", type=int, default=64, help="distinct batches walked (HBM-cold)")
     p.add_argument("--warm", action="store_true", help="re-use one batch (Infinity-Cache-warm)")
-    p.add_argument("--path", choices=["fused", "layers", "triplet"], default="fused",
-                   help="fused: one launch fwd+bwd (default); layers: Forward then Backward "
-                        "launches (the Layer API sequence); triplet: fused (q,a+,a-) step")
+    p.add_argument("--path", choices=["layers", "fused", "triplet"], default="layers",
+                   help="layers (default): Forward launch then Backward launch, the Layer API sequence; "
+                        "fused: one launch fwd+bwd (needs top_diff before the forward: not reachable from a "
+                        "Caffe Net); triplet: fused (q,a+,a-) step")
+    p.add_argument("--workload", choices=["cfg2", "cfg4", "cfg5"], default="cfg2",
+                   help="cfg2 (default, the metric's configuration); cfg5: 65,536 x 1024 fp16-storage pairs "
+                        "split over the ranks (strong scaling); cfg4: 1,517 candidates sharded -> all-gather "
+                        "of scores -> MAP/MRR on every rank (strong scaling)")
+    p.add_argument("--repeats", type=int, default=REPEATS)
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true")
@@ -137,21 +154,22 @@ def cpu_baseline(seconds):
 
 
 def load_traffic(path_name):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/),
-    collected and corrected by tools/pmc_traffic.py; None when absent."""
+    """HBM bytes per STEP from the committed rocprofv3 --pmc passes (profiles/traffic.json; separate
+    FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes, by tools/pmc_traffic.py);
+    None when absent."""
     f = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         d = json.load(open(f))
-        return d.get(path_name, {}).get("hbm_bytes_per_launch")
+        e = d.get(path_name, {})
+        return e.get("hbm_bytes_per_step", e.get("hbm_bytes_per_launch"))
     except Exception:
         return None
 
 
-def run(args):
+def init_dist(args):
     import torch
     import torch.distributed as dist
     from mms_answer_selection_amd import build, capi
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -174,52 +192,140 @@ def run(args):
     if world > 1:
         dist.barrier()
     capi.lib()
+    return torch, dist, capi, world, rank
 
-    G = max(1, args.group)
-    ring = 1 if args.warm else max(G, args.ring // G * G)
+
+def flush_caches(torch, mib=512):
+    """Untimed: overwrite `mib` MiB so that nothing of the ring is left in L2 / the 256-MiB Infinity Cache."""
+    scratch = torch.empty(mib << 18, device="cuda")
+    scratch.fill_(1.0)
+    torch.cuda.synchronize()
+    del scratch
+
+
+class Region:
+    """Steps [first, first+k) of the ring walk, cut into hipGraphs of at most G steps.  Step i reads ring
+    slot i % ring and writes its scores into row (i - chunk start) of a bucket; chunks alternate buckets."""
+
+    def __init__(self, torch, step, ring, G, buckets, use_graph):
+        self.torch, self.step, self.ring, self.G = torch, step, ring, G
+        self.buckets, self.use_graph = buckets, use_graph
+        self.graphs = {}
+        self.nchunk = 0
+
+    def chunks(self, first, k):
+        out, i = [], first
+        while k > 0:
+            c = min(self.G, k)
+            out.append((i, c))
+            i += c
+            k -= c
+        return out
+
+    def body(self, i0, cnt, bi):
+        b = self.buckets[bi]
+        for s in range(cnt):
+            self.step((i0 + s) % self.ring, b[s])
+
+    def capture(self, plan):
+        """Capture every (slot, count, bucket) graph `plan` (a list of chunk lists) will replay."""
+        if not self.use_graph:
+            return
+        torch = self.torch
+        n = 0
+        main = torch.cuda.current_stream()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(main)
+        with torch.cuda.stream(cap):
+            for chunks in plan:
+                for (i0, cnt) in chunks:
+                    key = (i0 % self.ring, cnt, n & 1)
+                    n += 1
+                    if key in self.graphs:
+                        continue
+                    gph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gph, stream=cap):
+                        self.body(i0, cnt, key[2])
+                    self.graphs[key] = gph
+        main.wait_stream(cap)
+        torch.cuda.synchronize()
+
+    def run(self, chunks, before=None, after=None):
+        for (i0, cnt) in chunks:
+            bi = self.nchunk & 1
+            self.nchunk += 1
+            if before:
+                before(bi)
+            if self.use_graph:
+                self.graphs[(i0 % self.ring, cnt, bi)].replay()
+            else:
+                self.body(i0, cnt, bi)
+            if after:
+                after(bi)
+
+
+def time_regions(torch, dist, world, main, repeats, run_one):
+    """Time `repeats` regions: barrier + synchronize on both sides of each, HIP events on the launch stream
+    inside the fences; returns the per-repeat milliseconds, MAX over ranks."""
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    ms, wall = [], []
+    for r in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence()
+        t0 = time.perf_counter()
+        e0.record(main)
+        run_one(r)
+        e1.record(main)
+        fence()
+        wall.append((time.perf_counter() - t0) * 1e3)
+        ms.append(e0.elapsed_time(e1))
+    t = torch.tensor(ms + wall, dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = t.tolist()
+    return t[:repeats], t[repeats:]
+
+
+def median(xs):
+    s = sorted(xs)
+    return s[len(s) // 2]
+
+
+def run(args):
+    torch, dist, capi, world, rank = init_dist(args)
+    if args.workload == "cfg5":
+        return run_cfg5(args, torch, dist, capi, world, rank)
+    if args.workload == "cfg4":
+        return run_cfg4(args, torch, dist, capi, world, rank)
+
+    K, Wm = args.steps, args.warmup
+    G = max(1, min(args.group, max(K, 1)))
+    ring = 1 if args.warm else max(2, args.ring)
     bt = Batches(torch, ring, args.path, rank)
     step = make_step(capi, bt, args.path)
-    ngroups = ring // G if not args.warm else 1
-
-    # score buckets: group g writes its G x 4096 scores into bucket g % 2
     buckets = [torch.empty(G, N_PAIRS, 1, 1, 1, device="cuda") for _ in range(2)]
     gathered = [torch.empty(world * G, N_PAIRS, 1, 1, 1, device="cuda") for _ in range(2)] if world > 1 else None
     comm = torch.cuda.Stream() if world > 1 else None
     bucket_free = [torch.cuda.Event() for _ in range(2)]   # gather of that bucket finished
     main = torch.cuda.current_stream()
-
-    def group_body(gi):
-        b = buckets[gi % 2]
-        for s in range(G):
-            slot = 0 if args.warm else (gi % ngroups) * G + s
-            step(slot, b[s])
-
-    # eager warm-up of every code path (also fills caches / instantiates kernels)
-    for gi in range(max(2, min(ngroups, 4))):
-        group_body(gi)
-    torch.cuda.synchronize()
-
-    graphs = {}
     use_graph = not args.no_graph
-    if use_graph:
-        # group gi uses ring slots (gi % ngroups) and bucket gi % 2 -> lcm(ngroups, 2) distinct graphs
-        period = ngroups if ngroups % 2 == 0 else ngroups * 2
-        cap = torch.cuda.Stream()
-        cap.wait_stream(main)
-        with torch.cuda.stream(cap):
-            for gi in range(period):
-                gph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gph, stream=cap):
-                    group_body(gi)
-                graphs[gi] = gph
-        main.wait_stream(cap)
-        torch.cuda.synchronize()
-    else:
-        period = 1
+    reg = Region(torch, step, ring, G, buckets, use_graph)
+
+    # eager pass over every code path (instantiates kernels), then the graphs of the warm-up and of
+    # every timed repeat -- all captured before anything is timed
+    reg.body(0, min(G, ring), 0)
+    torch.cuda.synchronize()
+    warm_chunks = reg.chunks(0, Wm)
+    rep_chunks = [reg.chunks(Wm + r * K, K) for r in range(args.repeats)]
+    reg.capture([warm_chunks] + rep_chunks)
 
     def gather_bucket(bi):
-        """All-gather of the per-pair scores of one bucket (GROUP steps x 4096 pairs per rank),
-        on the side stream, so it overlaps the next group's compute."""
+        """All-gather of the per-pair scores of one bucket (up to GROUP steps x 4096 pairs per rank), on the
+        side stream, so it overlaps the next chunk's compute."""
         comm.wait_stream(main)
         with torch.cuda.stream(comm):
             if args.backend == "nccl":
@@ -231,144 +337,303 @@ def run(args):
                 gathered[bi].view(-1).copy_(ho)
             bucket_free[bi].record(comm)
 
-    def run_group(gi):
-        if world > 1:
-            main.wait_event(bucket_free[gi % 2])      # previous gather of this bucket done
-        if use_graph:
-            graphs[gi % period].replay()
-        else:
-            group_body(gi)
-        if world > 1:
-            gather_bucket(gi % 2)
-
-    tails = {}
-
-    def tail_graph(gi, rem):
-        """A hipGraph of the first `rem` steps of group gi (a --steps / --warmup that is not a
-        multiple of GROUP must not fall back to host-paced launches inside the timed region)."""
-        key = (gi % period, rem)
-        if use_graph and key not in tails:
-            b = buckets[gi % 2]
-            cap2 = torch.cuda.Stream()
-            cap2.wait_stream(main)
-            with torch.cuda.stream(cap2):
-                gph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gph, stream=cap2):
-                    for s in range(rem):
-                        step(0 if args.warm else (gi % ngroups) * G + s, b[s])
-            main.wait_stream(cap2)
-            tails[key] = gph
-        return tails.get(key)
-
-    def run_steps(k, g0):
-        full, rem = divmod(k, G)
-        for i in range(full):
-            run_group(g0 + i)
-        if rem:                                        # time EXACTLY k steps
-            gi = g0 + full
-            b = buckets[gi % 2]
-            if world > 1:
-                main.wait_event(bucket_free[gi % 2])
-            gph = tail_graph(gi, rem)
-            if gph is not None:
-                gph.replay()
-            else:
-                for s in range(rem):
-                    step(0 if args.warm else (gi % ngroups) * G + s, b[s])
-            if world > 1:
-                gather_bucket(gi % 2)
-        return g0 + full + (1 if rem else 0)
-
-    # capture the partial groups this run will need BEFORE anything is timed
-    _fw, _rw = divmod(args.warmup, G)
-    if _rw:
-        tail_graph(_fw, _rw)
-    _g_after_warm = _fw + (1 if _rw else 0)
-    _fs, _rs = divmod(args.steps, G)
-    if _rs:
-        tail_graph(_g_after_warm + _fs, _rs)
-    torch.cuda.synchronize()
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+    before = (lambda bi: main.wait_event(bucket_free[bi])) if world > 1 else None
+    after = gather_bucket if world > 1 else None
 
     if world > 1:
-        # communicator set-up (lazy on the first collective) must not land in the timed region even
-        # when --warmup is 0: one untimed all-gather per bucket
+        # communicator set-up (lazy on the first collective) must not land in a timed region
         gather_bucket(0)
         gather_bucket(1)
-        fence()
-    g0 = run_steps(args.warmup, 0)
-    fence()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record(main)
-    run_steps(args.steps, g0)
-    e1.record(main)
-    fence()
-    t1 = time.perf_counter()
-    wall = t1 - t0
-    ev_ms = e0.elapsed_time(e1)
+        torch.cuda.synchronize()
+    if not args.warm:
+        flush_caches(torch)
+    reg.run(warm_chunks, before, after)
 
-    tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall = float(tmax.item())
+    def one(r):
+        reg.run(rep_chunks[r], before, after)
+        if world > 1:                                  # the last gathers belong to the region
+            main.wait_event(bucket_free[0])
+            main.wait_event(bucket_free[1])
+    ev_ms, wall_ms = time_regions(torch, dist, world, main, args.repeats, one)
+    t_ms = median(ev_ms)
 
     out = None
     if rank == 0:
         launches_per_step = {"fused": 1, "layers": 2, "triplet": 2}[args.path]
-        step_us_ev = ev_ms * 1e3 / args.steps            # HIP events on the launch stream
-        achieved = B_UNFUSED / (step_us_ev * 1e-6) / 1e9 if args.path != "triplet" else None
-        value = world * N_PAIRS * args.steps / wall
+        step_us = t_ms * 1e3 / K
+        achieved = B_UNFUSED / (step_us * 1e-6) / 1e9 if args.path != "triplet" else None
         kernel = {"fused": "mms::euclid_pair32_kernel<75,true,true,...> (SimCross Euclid fwd+bwd, one launch)",
-                  "layers": "mms::euclid_pair32_kernel<75,true,false,...> + <75,false,true,...>",
-                  "triplet": "mms::triplet_wave_kernel<3> + loss_finish_kernel"}[args.path]
+                  "layers": "mms::euclid_pair32_kernel<75,true,false,...> (Forward) then <75,false,true,...> (Backward)",
+                  "triplet": "mms::triplet32_kernel<75,...> + loss_finish_kernel"}[args.path]
+        mode = capi.get_euclid_backward_mode()
         out = {
             "metric": "QA pairs/sec (fwd+bwd) at batch 4096, 300-d; % HBM roofline",
-            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+            "value": world * N_PAIRS * K / (t_ms * 1e-3), "unit": "pairs/s", "n_gpus": world, "steps": K,
+            "warmup": Wm, "ms_per_step": t_ms / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cfg2: SimCross dist_mode=1 (Euclid) fwd+bwd, q,a (4096,1,300) fp32 per GPU",
                        "pairs_per_gpu": N_PAIRS, "dim": DIM, "global_batch": world * N_PAIRS,
                        "path": args.path, "launches_per_step": launches_per_step,
-                       "euclid_backward_arithmetic": capi.get_euclid_backward_mode() +
+                       "path_note": {"layers": "Forward launch, then Backward launch: the sequence a Caffe Net / "
+                                               "`caffe time` issues through the Layer API",
+                                     "fused": "ONE launch for forward+backward; needs top_diff before the forward "
+                                              "(not reachable from a Caffe Net; labelled variant)",
+                                     "triplet": "fused (q, a+, a-) SimCross x2 + PairRankLoss step"}[args.path],
+                       "euclid_backward_arithmetic": mode +
                        (" (scores bit-identical to the CPU code; gradient elements <= 2 ulp from it, bar 1e-5)"
-                        if capi.get_euclid_backward_mode() == "fp32" else " (gradients bit-identical too)"),
+                        if mode == "fp32" else " (gradients bit-identical too)"),
                        "residency": "cache-warm (1 batch)" if args.warm else
-                                    "HBM-cold ring of %d batches (%.2f GiB)" % (ring, ring * 19.7e6 / 2**30),
+                                    "HBM-cold: ring of %d batches (%.2f GiB), caches flushed before the warm-up, "
+                                    "timed steps continue the ring walk" % (ring, ring * 19.7e6 / 2**30),
                        "hip_graph_group": G if use_graph else 0,
+                       "clock": "HIP events on the launch stream inside barrier+synchronize fences, max over ranks; "
+                                "median of %d repeats of the %d-step region" % (args.repeats, K),
+                       "repeats_ms_per_step": [x / K for x in ev_ms],
+                       "host_wall_ms_per_step_median": median(wall_ms) / K,
+                       "ranks_seen": dist.get_world_size() if world > 1 else 1,
                        "parallelism": "pair-sharded x%d%s" % (
                            world, ", %s all-gather of scores per %d steps" % (
                                "RCCL" if args.backend == "nccl" else "host-staged gloo (rehearsal)", G)
                            if world > 1 else "")},
         }
         if achieved is not None:
+            traffic = load_traffic(args.path)
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.path),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac_real": (traffic / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "kernel": kernel,
-                "algorithmic_bytes_per_launch": B_UNFUSED if args.path == "fused" else None,
                 "algorithmic_bytes_per_step": B_UNFUSED,
-                "fused_compulsory_bytes_per_step": B_FUSED if args.path == "fused" else None,
-                "frac_vs_fused_bytes": (B_FUSED / (step_us_ev * 1e-6) / 1e9 / HBM_PEAK_GBS
-                                        if args.path == "fused" else None),
-                "avg_step_us_hip_events": step_us_ev,
-                "note": "duration = HIP events over the timed region / steps on rank 0 "
-                        "(launch-to-launch, includes inter-kernel gaps)"}
+                "algorithmic_bytes_per_launch": {"layers": [B_FWD, B_BWD], "fused": [B_UNFUSED]}[args.path],
+                "avg_step_us_hip_events": step_us,
+                "note": "achieved = SURVEY 8(d) unfused bytes per step / (median events time / steps), i.e. "
+                        "launch-to-launch including inter-kernel gaps; frac_real = PMC HBM bytes per step "
+                        "(profiles/traffic.json) over the same time"}
     if world > 1:
         dist.barrier()
 
+    # N > 1: the same walk with the scores all-gathered after EVERY step (no bucketing), for the record
+    if world > 1 and not args.no_variants:
+        K2 = min(K, 256)
+        reg1 = Region(torch, step, ring, 1, buckets, use_graph)
+        first = Wm + args.repeats * K
+        ch = [reg1.chunks(first + r * K2, K2) for r in range(3)]
+        reg1.capture(ch)
+
+        def one1(r):
+            reg1.run(ch[r], before, after)
+            main.wait_event(bucket_free[0])
+            main.wait_event(bucket_free[1])
+        ev1, _ = time_regions(torch, dist, world, main, 3, one1)
+        if rank == 0:
+            out["config"]["per_step_gather_variant"] = {
+                "ms_per_step": median(ev1) / K2, "value": world * N_PAIRS * K2 / (median(ev1) * 1e-3),
+                "note": "one all-gather of 4096 scores per rank after every step (16 KiB messages: latency-bound)"}
+
     # side measurements on rank 0 at N=1 only (not part of the timed region above)
     if rank == 0 and world == 1 and not args.no_variants:
+        out["roofline"].update(per_kernel_roofline(torch, capi)) if "roofline" in out else None
         out["variants"] = variants(torch, capi, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def per_kernel_roofline(torch, capi):
+    """The two launches of the Layer sequence timed on their own (HBM-cold ring, hipGraph of 32 launches,
+    events on the launch stream): SURVEY 8(d) bytes per launch / average launch-to-launch time."""
+    bt = Batches(torch, 64, "layers", 0)
+    top = torch.empty(64, N_PAIRS, 1, 1, 1, device="cuda")
+    res = {}
+    for name, nbytes, fn in (
+            ("forward", B_FWD, lambda i: capi.simcross_forward(1, bt.q[i], bt.a[i], top[i])),
+            ("backward", B_BWD, lambda i: capi.simcross_backward(1, bt.q[i], bt.a[i], top[i], bt.dT[i],
+                                                                   bt.dq[i], bt.da[i]))):
+        for i in range(64):
+            fn(i)
+        torch.cuda.synchronize()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        graphs = []
+        with torch.cuda.stream(cap):
+            for g0 in (0, 32):
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph, stream=cap):
+                    for i in range(g0, g0 + 32):
+                        fn(i)
+                graphs.append(gph)
+        torch.cuda.current_stream().wait_stream(cap)
+        flush_caches(torch)
+        ts = []
+        for rep in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for r in range(8):
+                graphs[r & 1].replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / 256)
+        us = median(ts)
+        res[name] = {"us_per_launch": us, "algorithmic_bytes": nbytes,
+                     "achieved_GBps": nbytes / (us * 1e-6) / 1e9,
+                     "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    return {"per_kernel_cold": res}
+
+
+def run_cfg5(args, torch, dist, capi, world, rank):
+    """BASELINE cfg 5: 65,536 pairs x 1024-d, fp16 storage / fp32 arithmetic, SimCross Euclid fwd+bwd, the batch
+    SPLIT over the ranks (strong scaling): every rank runs the fused launch on its contiguous shard and the
+    per-pair scores are all-gathered after every step (256 KiB in all) on a side stream, double-buffered."""
+    from mms_answer_selection_amd import sharded
+    NT, D = 65536, 1024
+    lo, hi = sharded.shard_range(NT, rank, world)
+    n = hi - lo
+    ring = max(2, min(16, (1 << 30) // (n * D * 2 * 4)))      # ~1 GiB of distinct shards per rank
+    g = torch.Generator(device="cuda").manual_seed(1701 + rank)
+    q = (torch.randn(ring, n, 1, D, device="cuda", generator=g) * 0.4).half()
+    a = (torch.randn(ring, n, 1, D, device="cuda", generator=g) * 0.4).half()
+    dT = torch.randn(ring, n, 1, 1, 1, device="cuda", generator=g)
+    dq, da = torch.empty_like(q), torch.empty_like(a)
+    tops = [torch.empty(n, 1, 1, 1, device="cuda") for _ in range(2)]
+    full = [torch.empty(NT, device="cuda") for _ in range(2)]
+    main = torch.cuda.current_stream()
+    comm = torch.cuda.Stream() if world > 1 else None
+    free = [torch.cuda.Event() for _ in range(2)]
+    K, Wm = args.steps, args.warmup
+    cnt = [0]
+
+    def step():
+        i = cnt[0]
+        cnt[0] += 1
+        bi = i & 1
+        if world > 1:
+            main.wait_event(free[bi])
+        s = i % ring
+        capi.simcross_euclid_forward_backward_f16(q[s], a[s], dT[s], tops[bi], dq[s], da[s])
+        if world > 1:
+            comm.wait_stream(main)
+            with torch.cuda.stream(comm):
+                if args.backend == "nccl":
+                    sharded.all_gather_scores(tops[bi].view(n), NT, out=full[bi])
+                else:
+                    full[bi].copy_(sharded.all_gather_scores(tops[bi].view(n).cpu(), NT))
+                free[bi].record(comm)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    flush_caches(torch)
+    for _ in range(Wm):
+        step()
+
+    def one(r):
+        for _ in range(K):
+            step()
+        if world > 1:
+            main.wait_event(free[0])
+            main.wait_event(free[1])
+    ev_ms, wall_ms = time_regions(torch, dist, world, main, args.repeats, one)
+    t_ms = median(ev_ms)
+    if rank == 0:
+        b_unfused = 2 * (3 * NT * 2 * D) + 4 * 3 * NT                 # SURVEY 8(d), s = 2, whole batch
+        step_us = t_ms * 1e3 / K
+        out = {"metric": "QA pairs/sec (fwd+bwd), cfg 5: 65,536 x 1024 fp16 storage; % HBM roofline",
+               "value": NT * K / (t_ms * 1e-3), "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": Wm,
+               "ms_per_step": t_ms / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f16 storage / f32 arithmetic", "data": "synthetic",
+               "config": {"workload": "cfg5: SimCross Euclid fwd+bwd, 65,536 pairs x 1024-d fp16 storage, batch split "
+                                      "over %d rank(s), scores all-gathered every step" % world,
+                          "pairs_total": NT, "pairs_per_gpu": n, "dim": D, "ranks_seen":
+                              dist.get_world_size() if world > 1 else 1,
+                          "repeats_ms_per_step": [x / K for x in ev_ms],
+                          "parallelism": "pair-sharded x%d (contiguous shards), %s" % (
+                              world, "RCCL all-gather per step" if args.backend == "nccl" else "gloo rehearsal")},
+               "roofline": {"bound": "hbm", "achieved": b_unfused / (step_us * 1e-6) / 1e9 / world,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": b_unfused / (step_us * 1e-6) / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
+                            "note": "per GPU: SURVEY 8(d) unfused bytes of the whole batch / ranks / step time"}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_cfg4(args, torch, dist, capi, world, rank):
+    """BASELINE cfg 4: scoring only.  1,517 candidates (40 x 40 word grids, Dw = 50: the TREC-QA test split) are
+    sharded over the ranks; each rank runs the SimCross forward on its shard and reduces every candidate's map to
+    one score; the scores are all-gathered and EVERY rank computes MAP and MRR over the 68 question groups on its
+    GPU.  Asserted before timing: the gathered scores equal the unsharded scoring bit for bit on every rank (hence
+    so does any ranking), and MAP / MRR agree across ranks."""
+    import numpy as np
+    from mms_answer_selection_amd import sharded
+    n, Wd, D, groups = 1517, 40, 50, 68
+    g = torch.Generator(device="cuda").manual_seed(1701)            # the SAME candidates on every rank
+    qa = torch.randn(n, Wd, D, device="cuda", generator=g) * 0.4
+    aa = torch.randn(n, Wd, D, device="cuda", generator=g) * 0.4
+    label = (torch.rand(n, device="cuda", generator=g) < 0.2).float()
+    grp = torch.sort(torch.randint(0, groups, (n,), device="cuda", generator=g).float()).values
+    lo, hi = sharded.shard_range(n, rank, world)
+    m = hi - lo
+    q, a = qa[lo:hi].contiguous(), aa[lo:hi].contiguous()
+    top = torch.empty(m, 1, Wd, Wd, device="cuda")
+    full = torch.empty(n, device="cuda")
+
+    def score_local():
+        capi.simcross_forward(1, q, a, top)
+        return top.view(m, -1).amax(dim=1)          # one score per candidate: its best word-pair similarity
+
+    def step():
+        s = score_local()
+        if world > 1:
+            if args.backend == "nccl":
+                sharded.all_gather_scores(s, n, out=full)
+            else:
+                full.copy_(sharded.all_gather_scores(s.cpu(), n))
+        else:
+            full.copy_(s)
+        prob = torch.stack([1 - full, full], 1).contiguous()
+        return capi.rank_map_mrr(prob, label, grp)
+
+    # ranking identity: sharded == unsharded, on every rank
+    mp, mrr, eff = step()
+    top_all = torch.empty(n, 1, Wd, Wd, device="cuda")
+    capi.simcross_forward(1, qa, aa, top_all)
+    ref = top_all.view(n, -1).amax(dim=1)
+    same = bool((full.view(torch.int32) == ref.view(torch.int32)).all().item())
+    flag = torch.tensor([1.0 if same else 0.0, mp, -mp, mrr, -mrr], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    f = flag.tolist()
+    identical = f[0] == 1.0 and f[1] == -f[2] and f[3] == -f[4]
+    if not identical:
+        raise SystemExit("cfg4: sharded scoring differs from the unsharded one (scores same=%s, MAP %r, MRR %r)"
+                         % (same, mp, mrr))
+    K, Wm = args.steps, args.warmup
+    for _ in range(Wm):
+        step()
+    main = torch.cuda.current_stream()
+    ev_ms, wall_ms = time_regions(torch, dist, world, main, args.repeats, lambda r: [step() for _ in range(K)])
+    t_ms = median(wall_ms)                          # step() ends with a device-to-host copy: host wall is the clock
+    if rank == 0:
+        out = {"metric": "candidates scored + ranked per second, cfg 4: 1,517 x (40 x 40 x 50) SimCross forward -> "
+                         "all-gather -> MAP/MRR",
+               "value": n * K / (t_ms * 1e-3), "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": Wm,
+               "ms_per_step": t_ms / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "cfg4: scoring only, 1,517 candidates sharded over %d rank(s)" % world,
+                          "candidates": n, "candidates_per_gpu": m, "groups": groups, "ranks_seen":
+                              dist.get_world_size() if world > 1 else 1,
+                          "ranking_identity": "gathered scores bit-identical to the unsharded scoring on every rank; "
+                                              "MAP %.6f / MRR %.6f equal on all ranks" % (mp, mrr),
+                          "clock": "host wall inside barrier+synchronize fences (the step ends with a D2H copy), "
+                                   "median of %d repeats" % args.repeats,
+                          "parallelism": "pair-sharded x%d, %s" % (
+                              world, "RCCL all-gather per step" if args.backend == "nccl" else "gloo rehearsal")}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -383,7 +648,7 @@ if DEFAULT_BWD_MODE not in ("fp32", "reference"):
 def variants(torch, capi, args):
     """Short interleaved measurements of the other entry points / residency, same device."""
     res = {}
-    K, G = 1024, 16
+    K, G = 512, 16
     for name, path, ring in (("fused_cold", "fused", 64), ("fused_warm", "fused", 1),
                              ("fused_cold_reference_rounding_bwd", "fused", 64),
                              ("layers_cold", "layers", 64), ("layers_warm", "layers", 1),
@@ -413,16 +678,23 @@ def variants(torch, capi, args):
                         step((gi * G + s) % ring, top[s])
                 graphs.append(gph)
         torch.cuda.current_stream().wait_stream(cap)
+        if ring > 1:
+            flush_caches(torch)
         for i in range(8):
             graphs[i % ng].replay()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(K // G):
-            graphs[i % ng].replay()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / K
+        ts = []
+        nxt = 8
+        for rep in range(5):                            # median of 5 repeats, continuing the ring walk
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(K // G):
+                graphs[(nxt + i) % ng].replay()
+            e1.record()
+            torch.cuda.synchronize()
+            nxt += K // G
+            ts.append(e0.elapsed_time(e1) * 1e3 / K)
+        us = median(ts)
         pairs = N_PAIRS
         res[name] = {"us_per_step": us, "pairs_per_s": pairs / (us * 1e-6)}
         if path != "triplet":

@@ -20,7 +20,10 @@
 // All products use v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate, each MFMA
 // bit-equal to a k-ordered fmaf chain -- no reduced-precision path.
 // Deterministic: split-K partial slabs are summed in a fixed order, no atomics.
+#include <type_traits>
+
 #include "mms_common.h"
+#include "panel_gemm.h"
 
 namespace mms {
 
@@ -1047,15 +1050,18 @@ int bilinear_backward(int N, int W1, int W2, int D, int M, const float* q, const
 
 // ---------------------------------- SimMatrix -------------------------------
 struct SimMatrixWs {
-  size_t u_off, part_off, total;
+  size_t u_off, part_off, wt_off, total;
   int ksplit, kchunk;
 };
 static SimMatrixWs simmatrix_ws(int N, int K1, int K2) {
   SimMatrixWs w{};
   w.ksplit = pick_ksplit(K1, K2, N, &w.kchunk);
+  int pchunk = 0;
+  const int psplit = panel_pick_ksplit((K1 + 63) / 64, 1, N, &pchunk);   // the panel kernel's split (if it runs)
   w.u_off = 0;
   w.part_off = round_up((size_t)N * K2 * sizeof(float), 256);
-  w.total = w.part_off + round_up((size_t)w.ksplit * K1 * K2 * sizeof(float), 256);
+  w.wt_off = w.part_off + round_up((size_t)(psplit > w.ksplit ? psplit : w.ksplit) * K1 * K2 * sizeof(float), 256);
+  w.total = w.wt_off + round_up((size_t)K1 * K2 * sizeof(float), 256);      // W^T for the dq product
   return w;
 }
 size_t simmatrix_workspace_bytes(int N, int K1, int K2) { return simmatrix_ws(N, K1, K2).total; }
@@ -1063,6 +1069,15 @@ size_t simmatrix_workspace_bytes(int N, int K1, int K2) { return simmatrix_ws(N,
 int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, const float* W,
                       float* top, float* qw, hipStream_t s) {
   // qw = Q W  (:60-61) ; top_i = a_i . qw_i  (:62-64)
+  {
+    // one launch: the row dot is the product's epilogue
+    PanelArgs p = panel_args(N, K2, K1, q, K1, W, K2, qw, K2);
+    p.Y = a; p.ldy = K2; p.rowdot = top; p.rd_stride = 1;
+    if (panel_eligible(p, true)) {
+      panel_launch(p, true, s);
+      return launch_status();
+    }
+  }
   GemmArgs g = gemm_args(N, K2, K1, q, K1, 1, W, K2, 1, qw, K2);
   gemm_launch(g, 1, s);
   hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a, qw, nullptr,
@@ -1083,6 +1098,20 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
     float* U = reinterpret_cast<float*>(base + lay.u_off);
     float* part = reinterpret_cast<float*>(base + lay.part_off);
     // dW += sum_i dT_i q_i a_i^T = Q^T (diag(dT) A)   (:73-80, accumulating)
+    bool dw_done = false;
+    {
+      PanelArgs p = panel_args(K1, K2, N, q, K1, a, K2, part, K2);
+      p.kscale = top_diff;                      // A(i, k = pair) = q_k[i] * dT_k
+      p.ksplit = panel_pick_ksplit(p.row_blocks, 1, N, &p.kchunk);
+      p.c_ks = (long long)K1 * K2;
+      if (p.ksplit > 1 && panel_eligible(p, false)) {
+        panel_launch(p, false, s);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks((long long)K1 * K2)), dim3(256), 0, s,
+                           part, p.ksplit, (long long)K1 * K2, dW, 1);
+        dw_done = true;
+      }
+    }
+    if (!dw_done) {
     GemmArgs g = gemm_args(K1, K2, N, q, 1, K1, a, K2, 1, part, K2);
     g.ksplit = lay.ksplit; g.kchunk = lay.kchunk; g.c_ks = (long long)K1 * K2;
     g.bkscale = top_diff;                       // B(k = pair, j) = dT_k * a_k[j], scaled on load
@@ -1095,15 +1124,34 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
     gemm_launch(g, 1, s);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks((long long)K1 * K2)), dim3(256), 0, s,
                        part, lay.ksplit, (long long)K1 * K2, dW, 1);
+    }
   }
+  bool da_done = false;
   if (pd0) {
     // dq_j = dT_j * (W a_j)   (:88, NoTrans, beta 0)
-    GemmArgs g = gemm_args(N, K1, K2, a, K2, 1, W, 1, K2, dq, K1);
-    g.rowscale = top_diff;
-    g.stream_c = 1;                             // read next by another layer, not by this call
-    gemm_launch(g, 1, s);
+    float* Wt = (ws && ws_bytes >= lay.total) ? reinterpret_cast<float*>(static_cast<char*>(ws) + lay.wt_off) : nullptr;
+    PanelArgs p = panel_args(N, K1, K2, a, K2, Wt, K1, dq, K1);     // B(k, n) = W[n][k] = Wt[k][n]
+    p.rowscale = top_diff;
+    p.stream_c = 1;                             // read next by another layer, not by this call
+    if (pd1 && qw && K2 <= 304) {
+      // da_j = dT_j * (row j of the forward's Q.W): a streaming pass with no arithmetic to speak of, carried
+      // by this product's loader waves while its compute waves keep the matrix pipe busy
+      p.side_in = qw; p.side_out = da; p.side_scale = top_diff; p.side_ld = K2; p.side_cols = K2;
+    }
+    if (Wt && panel_eligible(p, true)) {
+      hipLaunchKernelGGL(pg_transpose_kernel, dim3((K2 + 31) / 32, (K1 + 31) / 32), dim3(256), 0, s, W, Wt, K1, K2);
+      panel_launch(p, true, s);
+      da_done = p.side_in != nullptr;
+    } else {
+      GemmArgs g = gemm_args(N, K1, K2, a, K2, 1, W, 1, K2, dq, K1);
+      g.rowscale = top_diff;
+      g.stream_c = 1;
+      gemm_launch(g, 1, s);
+    }
   }
-  if (pd1 && qw) {
+  if (da_done) {
+    // written by the dq launch
+  } else if (pd1 && qw) {
     if ((K2 & 3) == 0 && aligned16(qw) && aligned16(da)) {
       hipLaunchKernelGGL(rowscale4_kernel, dim3(ew_blocks((long long)N * (K2 / 4))), dim3(256), 0, s,
                          reinterpret_cast<const float4*>(qw), top_diff, reinterpret_cast<float4*>(da),
@@ -1115,10 +1163,17 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
     }
   } else if (pd1) {
     // da_j = dT_j * (W^T q_j)   (:88, Trans, beta 0)
-    GemmArgs g = gemm_args(N, K2, K1, q, K1, 1, W, K2, 1, da, K2);
-    g.rowscale = top_diff;
-    g.stream_c = 1;                             // read next by another layer, not by this call
-    gemm_launch(g, 1, s);
+    PanelArgs p = panel_args(N, K2, K1, q, K1, W, K2, da, K2);
+    p.rowscale = top_diff;
+    p.stream_c = 1;                             // read next by another layer, not by this call
+    if (panel_eligible(p, true)) {
+      panel_launch(p, true, s);
+    } else {
+      GemmArgs g = gemm_args(N, K2, K1, q, K1, 1, W, K2, 1, da, K2);
+      g.rowscale = top_diff;
+      g.stream_c = 1;
+      gemm_launch(g, 1, s);
+    }
   }
   return launch_status();
 }

@@ -91,3 +91,25 @@ def all_reduce_loss(local_sum, n_total, group=None):
     t = local_sum.clone()
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t / float(n_total)
+
+
+def shard_loss_weight(loss_weight, n_local, n_total):
+    """The `top_diff` / `loss_weight` to hand a PairRankLoss backward (mms_pairrank_backward_f32) or the fused
+    triplet step (mms_triplet_euclid_step_f32) that runs on ONE RANK'S SHARD of the batch.
+
+    The reference scales every gradient element by top_diff / bottom[0]->count() -- the count of the WHOLE
+    batch (pair_rank_loss_layer.cpp:62-64).  The C ABI divides by the count it is given, which on a shard is
+    the local count, so an unscaled call would return gradients world_size times too large.  Passing
+    loss_weight * n_local / n_total restores the reference's scale: (w * n_local / n_total) / n_local = w / n_total.
+    The shard's LOSS output is then (w * n_local / n_total) * mean_local; summing it over ranks
+    (all_reduce_shard_losses) gives w * mean over the whole batch."""
+    if n_total <= 0 or n_local < 0 or n_local > n_total:
+        raise ValueError("shard of %d pairs out of %d" % (n_local, n_total))
+    return float(loss_weight) * float(n_local) / float(n_total)
+
+
+def all_reduce_shard_losses(local_loss, group=None):
+    """Sum of the per-shard losses produced with shard_loss_weight(): the loss of the whole batch."""
+    t = local_loss.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t

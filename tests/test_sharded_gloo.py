@@ -62,6 +62,80 @@ def _worker(rank, world, port, n, ret):
         dist.destroy_process_group()
 
 
+def _loss_worker(rank, world, port, n, ret):
+    """PairRankLoss (and its gradients back through SimMatrix, whose dW is a shared parameter) on pair shards:
+    with shard_loss_weight() the sharded gradients equal the unsharded ones."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mms_answer_selection_amd import sharded
+        from oracle import cpu_oracle as O
+        K, margin, w = 10, 0.3, 1.0
+        r = rng(21)
+        q = (r.standard_normal((n, K)) * 0.4).astype(np.float32)
+        ap = (r.standard_normal((n, K)) * 0.4).astype(np.float32)
+        an = (r.standard_normal((n, K)) * 0.4).astype(np.float32)
+        Wt = r.uniform(-0.5, 0.5, (K, K)).astype(np.float32)
+        y = (r.uniform(size=(n, 1)) < 0.7).astype(np.float32)
+
+        def chain(qs, aps, ans, ys, top_diff):
+            sp, _ = O.simmatrix_forward(qs, aps, Wt)
+            sn, _ = O.simmatrix_forward(qs, ans, Wt)
+            loss, od, sd = O.pairrank_forward(sp, sn, ys, margin)
+            dsp, dsn = O.pairrank_backward(ys, od, sd, top_diff)
+            dq1, dap, dW1 = O.simmatrix_backward(qs, aps, Wt, dsp)
+            dq2, dan, dW2 = O.simmatrix_backward(qs, ans, Wt, dsn)
+            return loss, dq1 + dq2, dap, dan, dW1 + dW2
+
+        loss_ref, dq_ref, dap_ref, dan_ref, dW_ref = chain(q, ap, an, y, w)
+        lo, hi = sharded.shard_range(n, rank, world)
+        ok = [True] * 4
+        if hi > lo:
+            tw = sharded.shard_loss_weight(w, hi - lo, n)
+            loss, dq, dap, dan, dW = chain(q[lo:hi], ap[lo:hi], an[lo:hi], y[lo:hi], tw)
+            tol = dict(rtol=2e-5, atol=1e-7)
+            ok[0] = bool(np.allclose(dq, dq_ref[lo:hi], **tol) and np.allclose(dap, dap_ref[lo:hi], **tol)
+                         and np.allclose(dan, dan_ref[lo:hi], **tol))
+            # the UNSCALED call is world_size times too large: the hazard the helper exists for
+            _, dq_bad, _, _, _ = chain(q[lo:hi], ap[lo:hi], an[lo:hi], y[lo:hi], w)
+            if np.abs(dq_ref[lo:hi]).max() > 0 and (hi - lo) != n:
+                ok[1] = not np.allclose(dq_bad, dq_ref[lo:hi], **tol)
+            lt = torch.tensor([float(loss) * tw])
+        else:
+            dW = np.zeros_like(Wt)
+            lt = torch.zeros(1)
+        dWt = torch.from_numpy(np.ascontiguousarray(dW))
+        sharded.all_reduce_param_grads([dWt])
+        ok[2] = bool(np.allclose(dWt.numpy(), dW_ref, rtol=2e-5, atol=1e-6))
+        tot = sharded.all_reduce_shard_losses(lt)
+        ok[3] = abs(float(tot) - float(loss_ref) * w) < 1e-5
+        ret[rank] = tuple(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [8, 7])
+def test_world2_sharded_loss_gradients(n, oracle):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_loss_worker, args=(world, _free_port(), n, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rk in range(world):
+        assert all(ret[rk]), (rk, ret[rk])
+
+
+def test_shard_loss_weight_rejects_nonsense():
+    from mms_answer_selection_amd import sharded
+    assert sharded.shard_loss_weight(2.0, 512, 4096) == 0.25
+    with pytest.raises(ValueError):
+        sharded.shard_loss_weight(1.0, 5, 4)
+
+
 @pytest.mark.parametrize("n", [8, 7, 1])     # even, ragged, fewer pairs than ranks
 def test_world2_gloo(n, oracle):
     world = 2

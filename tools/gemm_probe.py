@@ -13,5 +13,5 @@ dT = torch.randn(N, 1, device="cuda", generator=g)
 dq = torch.empty_like(q); da = torch.empty_like(a); dW = torch.zeros_like(W)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     capi.simmatrix_forward(q, a, W, top, scratch)
-    capi.simmatrix_backward(q, a, W, dT, dq, da, dW)
+    capi.simmatrix_backward(q, a, W, dT, dq, da, dW, qw=scratch if os.environ.get('MMS_PROBE_CACHED', '1') == '1' else None)
 torch.cuda.synchronize()

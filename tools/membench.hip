@@ -60,6 +60,44 @@ __global__ __launch_bounds__(256) void read2_kernel(const float4* __restrict__ q
   if (s == 12345.678f) out[i] = s;
 }
 
+__global__ __launch_bounds__(512) void empty_kernel(int n) {}
+// read q, a (cold), write one float per pair: the data movement of a forward-only launch
+__global__ __launch_bounds__(512) void read2_pair_kernel(const float4* __restrict__ q, const float4* __restrict__ a,
+                                                         float* __restrict__ top, int n) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = min((blockIdx.x * 8 + wave) * 2 + (lane >> 5), n - 1), j = lane & 31;
+  const size_t b = (size_t)row * D4;
+  float4 x[3], y[3];
+#pragma unroll
+  for (int it = 0; it < 3; ++it) { int i = j + 32 * it; int ii = i < D4 ? i : 0; x[it] = q[b + ii]; y[it] = a[b + ii]; }
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < 3; ++it) s += (x[it].x - y[it].x) + (x[it].y - y[it].y) + (x[it].z - y[it].z) + (x[it].w - y[it].w);
+  for (int o = 16; o; o >>= 1) s += __shfl_xor(s, o);
+  if (j == 0) top[row] = s;
+}
+// read q, a (just read by the launch before: L2 / Infinity Cache), top, dT; write dq, da with streaming stores:
+// the data movement of a backward-only launch
+__global__ __launch_bounds__(512) void bwd_like_kernel(const float4* __restrict__ q, const float4* __restrict__ a,
+                                                       const float* __restrict__ top, const float* __restrict__ dT,
+                                                       float4* __restrict__ dq, float4* __restrict__ da, int n) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = min((blockIdx.x * 8 + wave) * 2 + (lane >> 5), n - 1), j = lane & 31;
+  const size_t b = (size_t)row * D4;
+  float4 x[3], y[3];
+#pragma unroll
+  for (int it = 0; it < 3; ++it) { int i = j + 32 * it; int ii = i < D4 ? i : 0; x[it] = q[b + ii]; y[it] = a[b + ii]; }
+  const float c = top[row] * dT[row];
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    int i = j + 32 * it;
+    if (i < D4) {
+      __builtin_nontemporal_store((v4f_nt){c * (x[it].x - y[it].x), c * (x[it].y - y[it].y), c * (x[it].z - y[it].z), c * (x[it].w - y[it].w)}, (v4f_nt*)(dq + b + i));
+      __builtin_nontemporal_store((v4f_nt){c * (y[it].x - x[it].x), c * (y[it].y - x[it].y), c * (y[it].z - x[it].z), c * (y[it].w - x[it].w)}, (v4f_nt*)(da + b + i));
+    }
+  }
+}
+
 struct Slot { float *q, *a, *dT, *top, *dq, *da; };
 
 int main(int argc, char** argv) {
@@ -123,5 +161,16 @@ int main(int argc, char** argv) {
     mms_simcross_forward_f32(1, N, 1, 1, D, 1, x.q, x.a, nullptr, nullptr, x.top, nullptr, nullptr, nullptr, 0, t); }, 2.0 * nb);
   run("mms bwd", [&](Slot& x, hipStream_t t) {
     mms_simcross_backward_f32(1, N, 1, 1, D, 1, x.q, x.a, nullptr, 0, x.top, x.dT, nullptr, nullptr, 1, 1, x.dq, x.da, nullptr, nullptr, nullptr, 0, t); }, 4.0 * nb);
+  run("2 empty launches", [&](Slot& x, hipStream_t t) {
+    hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(512), 0, t, N);
+    hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(512), 0, t, N); }, 0.0);
+  run("read2 pair-structured", [&](Slot& x, hipStream_t t) {
+    hipLaunchKernelGGL(read2_pair_kernel, dim3((N + 15) / 16), dim3(512), 0, t, (const float4*)x.q, (const float4*)x.a, x.top, N); }, 2.0 * nb);
+  run("SEQ read2 + bwd-like (2 launches)", [&](Slot& x, hipStream_t t) {
+    hipLaunchKernelGGL(read2_pair_kernel, dim3((N + 15) / 16), dim3(512), 0, t, (const float4*)x.q, (const float4*)x.a, x.top, N);
+    hipLaunchKernelGGL(bwd_like_kernel, dim3((N + 15) / 16), dim3(512), 0, t, (const float4*)x.q, (const float4*)x.a, x.top, x.dT, (float4*)x.dq, (float4*)x.da, N); }, 6.0 * nb);
+  run("SEQ mms fwd + mms bwd (2 launches)", [&](Slot& x, hipStream_t t) {
+    mms_simcross_forward_f32(1, N, 1, 1, D, 1, x.q, x.a, nullptr, nullptr, x.top, nullptr, nullptr, nullptr, 0, t);
+    mms_simcross_backward_f32(1, N, 1, 1, D, 1, x.q, x.a, nullptr, 0, x.top, x.dT, nullptr, nullptr, 1, 1, x.dq, x.da, nullptr, nullptr, nullptr, 0, t); }, 6.0 * nb);
   return 0;
 }
