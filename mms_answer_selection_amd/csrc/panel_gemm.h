@@ -102,6 +102,19 @@ __device__ __forceinline__ void pg_dma4(const float* gsrc, unsigned lds_byte) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
 }
 
+#ifdef MMS_PG_STAMPS      // dev-only (tools/panelbench.hip): per-workgroup shader-clock / wall-clock stamps around the main loop
+__device__ unsigned long long* pg_stamp_buf = nullptr;
+#define PG_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    if (pg_stamp_buf && threadIdx.x == 0) {                                                           \
+      pg_stamp_buf[(size_t)blockIdx.x * 8 + 2 * (k)] = __builtin_amdgcn_s_memtime();                  \
+      pg_stamp_buf[(size_t)blockIdx.x * 8 + 2 * (k) + 1] = __builtin_amdgcn_s_memrealtime();          \
+    }                                                                                                 \
+  } while (0)
+#else
+#define PG_STAMP(k) do {} while (0)
+#endif
+
 template <int NT, bool A_KC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void panel_gemm_kernel(PanelArgs p) {
   using G = PanelGeom<NT, A_KC>;
@@ -187,64 +200,111 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int tt = 0; tt < NT; ++tt) acc[tt] = (pg_v4f){0.f, 0.f, 0.f, 0.f};
 
-  // One k-tile: 8 MFMA steps (h, i) x NT column tiles.  Full tiles are software-pipelined by hand: the B
-  // operands of step s+1 are read from LDS into a second register set BEFORE the NT MFMAs of step s issue
-  // (left to itself the compiler emits read -> wait -> two MFMAs, exposing one LDS latency per pair).
-  auto compute = [&](auto tail_tag, int stage, int k0) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
-    const float* Bs = lds + stage * STAGE_F;
-    const float* At = Bs + G::B_F;
-    pg_v4f av[2];
+  // One k-tile = 8 MFMA steps (h, i) x NT column tiles.  The compute waves' stream is software-pipelined by
+  // hand across steps AND across tiles: while the NT MFMAs of step s issue, the B operands of step s+1 are
+  // read from LDS into a second register set, one LDS read in the shadow of each MFMA; the barrier that
+  // publishes tile T+1 sits in front of step 7 of tile T (every LDS read of tile T has completed by then: its
+  // step-7 operands are already in registers), so the first operands of tile T+1 -- its A fragments and its
+  // step-0 B row -- are fetched beside the last MFMAs of tile T.  (Left to itself the compiler emits
+  // read -> wait -> two MFMAs; all reads first, then all MFMAs, idles the matrix pipe while the reads issue.)
+  pg_v4f av[2];
+  float bv[2][NT];
+#ifdef MMS_PG_STAMPS
+  unsigned long long pg_wait_lgkm = 0, pg_wait_bar = 0;
+#endif
+  auto read_a = [&](pg_v4f (&dst)[2], int stage) {
+    const float* At = lds + stage * STAGE_F + G::B_F;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (A_KC) {
-        av[h] = *reinterpret_cast<const pg_v4f*>(At + (wave * 16 + r) * PG_LDA + 16 * h + 4 * g);
+        dst[h] = *reinterpret_cast<const pg_v4f*>(At + (wave * 16 + r) * PG_LDA + 16 * h + 4 * g);
       } else {
         const float* sc = At + G::A_F;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          av[h][i] = At[(16 * h + 4 * g + i) * PG_LDT + wave * 16 + r] * sc[16 * h + 4 * g + i];
+          dst[h][i] = At[(16 * h + 4 * g + i) * PG_LDT + wave * 16 + r] * sc[16 * h + 4 * g + i];
       }
     }
+  };
+  auto read_b = [&](float (&dst)[NT], int stage, int st) {
+    const float* bn = lds + stage * STAGE_F + (16 * (st >> 2) + 4 * g + (st & 3)) * LD + r;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) dst[tt] = bn[16 * tt];
+  };
+  auto interleave = [&]() {                          // issue order: one LDS read in the shadow of each MFMA
+#pragma unroll
+    for (int u = 0; u < (NT + 1) / 2; ++u) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NT - (NT + 1) / 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // what is left of the reads (A fragments)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // A full tile whose operands of step 0 (av, bv[0]) are already in registers.  BAR: tile T+1 exists (the
+  // barrier that publishes it is taken in front of step 7); PRE: tile T+1 is a full tile, prefetch its first
+  // operands beside step 7.
+  auto full_tile = [&](auto bar_tag, auto pre_tag, int stage, int nstage) {
+    constexpr bool BAR = decltype(bar_tag)::value, PRE = decltype(pre_tag)::value;
 #if defined(MMS_PG_ABLATE) && MMS_PG_ABLATE >= 2      // dev-only timing ablation: MFMAs alone, operands from registers
-    if (!TAIL) {
 #pragma unroll
-      for (int st = 0; st < 8; ++st)
+    for (int st = 0; st < 8; ++st) {
+      if (st == 7 && BAR) asm volatile("s_barrier" ::: "memory");
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
-          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st >> 2][st & 3], av[(st >> 2) ^ 1][st & 3], acc[tt], 0, 0, 0);
-      return;
+      for (int tt = 0; tt < NT; ++tt)
+        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st >> 2][st & 3], av[(st >> 2) ^ 1][st & 3], acc[tt], 0, 0, 0);
     }
+    return;
 #endif
-    if (!TAIL) {
-      float bv[2][NT];
-      const float* b0 = Bs + (4 * g) * LD + r;
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) bv[0][tt] = b0[16 * tt];
+    for (int st = 0; st < 7; ++st) {
+      read_b(bv[(st + 1) & 1], stage, st + 1);
 #pragma unroll
-      for (int st = 0; st < 8; ++st) {
-        if (st + 1 < 8) {
-          const float* bn = Bs + (16 * ((st + 1) >> 2) + 4 * g + ((st + 1) & 3)) * LD + r;
-#pragma unroll
-          for (int tt = 0; tt < NT; ++tt) bv[(st + 1) & 1][tt] = bn[16 * tt];
-        }
-        __builtin_amdgcn_sched_barrier(0);           // keep the reads above the MFMAs they run beside
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
-          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st >> 2][st & 3], bv[st & 1][tt], acc[tt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      return;
+      for (int tt = 0; tt < NT; ++tt)
+        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st >> 2][st & 3], bv[st & 1][tt], acc[tt], 0, 0, 0);
+      interleave();
     }
-    // the partial tile that ends a segment: k values past kend are zeroed in BOTH operands (the LDS rows
-    // behind them hold whatever the clamped DMA fetched)
+#ifdef MMS_PG_STAMPS
+    const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+    if (BAR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long tb1 = __builtin_amdgcn_s_memtime();
+    if (BAR) asm volatile("s_barrier" ::: "memory");
+    const unsigned long long tb2 = __builtin_amdgcn_s_memtime();
+    pg_wait_lgkm += tb1 - tb0; pg_wait_bar += tb2 - tb1;
+#else
+    if (BAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // B_{T+1}
+#endif
+    pg_v4f an[2];
+    if (PRE) {
+      read_a(an, nstage);
+      read_b(bv[0], nstage, 0);
+    }
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+      acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][3], bv[1][tt], acc[tt], 0, 0, 0);
+    interleave();
+    if (PRE) {
+      av[0] = an[0]; av[1] = an[1];
+      // pin the prefetch in THIS tile: hipcc otherwise sinks these loads across the loop's back edge, next to
+      // their uses in step 0 of the next tile (read -> wait -> MFMA again)
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) asm volatile("" : "+v"(bv[0][tt]));
+      asm volatile("" : "+v"(av[0]), "+v"(av[1]));
+    }
+  };
+  // The partial tile that ends a segment (K % 32 != 0): k values past kend are zeroed in BOTH operands (the
+  // LDS rows behind them hold whatever the clamped DMA fetched).  Not pipelined: one per segment.
+  auto tail_tile = [&](int stage, int k0) {
+    const float* Bs = lds + stage * STAGE_F;
+    pg_v4f at[2];
+    read_a(at, stage);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (k0 + 16 * h >= kend) continue;              // wave-uniform
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool ok = k0 + 16 * h + 4 * g + i < kend;
-        const float a1 = ok ? av[h][i] : 0.f;
+        const float a1 = ok ? at[h][i] : 0.f;
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
           float b1 = Bs[(16 * h + 4 * g + i) * LD + r + 16 * tt];
@@ -268,6 +328,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int NCC = (4 * NT + 15) / 16;
   pg_v4f y4[4][NCC];                                  // loaders, row dot: Y rows g + 4 rr of this wave's block
   if (loader) {
+    // A loader issues ~100 instructions per tile, its SIMD partner 250: at equal priority the younger loader
+    // waited ~450 cycles per DMA for an issue slot (the loaders, not the matrix pipe, then paced the kernel)
+    __builtin_amdgcn_s_setprio(3);
     if (p.Y) {                                        // issued first, consumed in the epilogue
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
@@ -311,8 +374,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       issue_next(0);
       issue_next(1);
     }
+#ifdef MMS_PG_STAMPS
+    unsigned long long ld_wait = 0, ld_bar = 0, ld_issue = 0;
+#endif
     for (int T = 0; T < ntiles; ++T) {
+#ifdef MMS_PG_STAMPS
+      const unsigned long long l0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
+      const unsigned long long l1 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_barrier" ::: "memory");
+      const unsigned long long l2 = __builtin_amdgcn_s_memtime();
+      if (T > 0) { ld_wait += l1 - l0; ld_bar += l2 - l1; }
+#else
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPT) : "memory");       // B_T
+#endif
       if (p.side_in) {
         if (T >= 1 && T <= 4) side_store(T - 1);
         if (T < 4) side_load(T);
@@ -321,7 +396,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (false)
 #endif
       issue_next((T + 2) % 3);
+#ifdef MMS_PG_STAMPS
+      if (T > 0) ld_issue += __builtin_amdgcn_s_memtime() - l2;
+#endif
     }
+#ifdef MMS_PG_STAMPS
+    if (pg_stamp_buf && threadIdx.x == 256) {
+      pg_stamp_buf[(size_t)(gridDim.x + blockIdx.x) * 8 + 0] = ld_wait;
+      pg_stamp_buf[(size_t)(gridDim.x + blockIdx.x) * 8 + 1] = ld_bar;
+      pg_stamp_buf[(size_t)(gridDim.x + blockIdx.x) * 8 + 2] = ld_issue;
+    }
+#endif
     if (p.side_in) {                                  // what the loop was too short for
       const int done_load = ntiles < 4 ? ntiles : 4;
       const int done_store = (ntiles < 5 ? ntiles : 5) > 0 ? (ntiles < 5 ? ntiles : 5) - 1 : 0;
@@ -332,20 +417,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   } else {
+    // Barriers: B_0 here, B_{T+1} inside tile T (full tiles: in front of step 7; a partial tile: behind it).
     int T = 0;
+    PG_STAMP(0);
+    if (ntiles > 0) asm volatile("s_barrier" ::: "memory");                              // B_0
+    bool primed = false;                               // are tile T's first operands in registers?
     for (int seg = 0; seg < p.nseg; ++seg) {
       int k0 = kbeg;
-      for (int f = 0; f < nfull; ++f, k0 += 32) {
-        asm volatile("s_barrier" ::: "memory");                                         // B_T
-        compute(std::false_type{}, T % 3, k0);
-        ++T;
+      for (int f = 0; f < nfull; ++f, k0 += 32, ++T) {
+        if (!primed) {
+          read_a(av, T % 3);
+          read_b(bv[0], T % 3, 0);
+        }
+        const bool next_exists = T + 1 < ntiles;
+        const bool next_full = next_exists && !(has_tail && f == nfull - 1);
+        if (next_full) full_tile(std::true_type{}, std::true_type{}, T % 3, (T + 1) % 3);
+        else if (next_exists) full_tile(std::true_type{}, std::false_type{}, T % 3, (T + 1) % 3);
+        else full_tile(std::false_type{}, std::false_type{}, T % 3, (T + 1) % 3);
+        primed = next_full;
       }
       if (has_tail) {
-        asm volatile("s_barrier" ::: "memory");                                         // B_T
-        compute(std::true_type{}, T % 3, k0);
+        tail_tile(T % 3, k0);
         ++T;
+        if (T < ntiles) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B_T of the next segment's first tile
+        primed = false;
       }
     }
+    PG_STAMP(1);
   }
   // ---- epilogue: accumulators -> LDS (16 x LD slice per compute wave) -> 256-byte row segments ----------
   if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMAs (and side job) have landed
@@ -412,6 +510,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   }
+#ifdef MMS_PG_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (pg_stamp_buf && threadIdx.x == 0) {
+    pg_stamp_buf[(size_t)blockIdx.x * 8 + 6] = pg_wait_lgkm;
+    pg_stamp_buf[(size_t)blockIdx.x * 8 + 7] = pg_wait_bar;
+  }
+#endif
+  PG_STAMP(2);
 }
 
 // ------------------------------------------------ host side -----------------------------------------

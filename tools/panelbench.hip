@@ -27,6 +27,42 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dT, h.data(), N * 4, hipMemcpyHostToDevice));
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+#ifdef MMS_PG_STAMPS
+  unsigned long long* sb; CK(hipMalloc(&sb, 1024 * 8 * 8)); CK(hipMemset(sb, 0, 1024 * 8 * 8));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(pg_stamp_buf), &sb, sizeof(sb)));
+  auto dump = [&](const char* name) {
+    std::vector<unsigned long long> h(1024 * 8);
+    CK(hipMemcpy(h.data(), sb, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> clk, loop_us, epi_us, wl, wb;
+    for (int b = 0; b < 256; ++b) {
+      const unsigned long long* x = &h[(size_t)b * 8];
+      if (!x[0] || !x[2]) continue;
+      clk.push_back((double)(x[2] - x[0]) / (double)(x[3] - x[1]) * 100.0);      // MHz: s_memrealtime ticks at 100 MHz
+      loop_us.push_back((double)(x[3] - x[1]) / 100.0);
+      epi_us.push_back((double)(x[5] - x[3]) / 100.0);
+      wl.push_back((double)x[6]); wb.push_back((double)x[7]);
+    }
+    std::sort(clk.begin(), clk.end()); std::sort(loop_us.begin(), loop_us.end()); std::sort(epi_us.begin(), epi_us.end());
+    {
+      std::vector<double> a0, a1, a2;
+      for (int b = 0; b < 512; ++b) {                 // loader stamps live at (gridDim.x + block): find non-zero triples past the compute ones
+        const unsigned long long* x = &h[(size_t)b * 8];
+        if (x[0] + x[1] + x[2] && !x[3] && !x[4] && !x[5] && !x[6] && !x[7]) { a0.push_back((double)x[0]); a1.push_back((double)x[1]); a2.push_back((double)x[2]); }
+      }
+      std::sort(a0.begin(), a0.end()); std::sort(a1.begin(), a1.end()); std::sort(a2.begin(), a2.end());
+      if (!a0.empty()) printf("   loader wave 4 (cycles over tiles 1..): vmcnt wait median %.0f, barrier wait median %.0f, issue+side median %.0f\n", a0[a0.size() / 2], a1[a1.size() / 2], a2[a2.size() / 2]);
+    }
+    std::sort(wl.begin(), wl.end()); std::sort(wb.begin(), wb.end());
+    if (!wl.empty()) printf("   in-loop waits of wave 0 (cycles over all tiles): lgkmcnt(0) before the barrier median %.0f, barrier median %.0f max %.0f\n", wl[wl.size() / 2], wb[wb.size() / 2], wb.back());
+    if (!clk.empty())
+      printf("   stamps %-30s shader clock median %.0f MHz (min %.0f max %.0f); main loop median %.2f us max %.2f; epilogue median %.2f us max %.2f\n",
+             name, clk[clk.size() / 2], clk.front(), clk.back(), loop_us[loop_us.size() / 2], loop_us.back(),
+             epi_us[epi_us.size() / 2], epi_us.back());
+    CK(hipMemset(sb, 0, 1024 * 8 * 8));
+  };
+#else
+  auto dump = [&](const char*) {};
+#endif
   auto run = [&](const char* name, auto&& body, double flop) {
     body(); CK(hipStreamSynchronize(st));
     hipGraph_t g; hipGraphExec_t ge;
@@ -42,8 +78,10 @@ int main(int argc, char** argv) {
     }
     std::sort(t.begin(), t.end());
     printf("%-34s median %8.2f us  min %8.2f   %6.1f TFLOP/s\n", name, t[2], t[0], flop / t[2] / 1e6);
+    dump(name);
   };
   const double fl = 2.0 * N * K * K;
+
   run("fwd  Q.W + rowdot", [&] {
     PanelArgs p = panel_args(N, K, K, q, K, W, K, qw, K); p.Y = a; p.ldy = K; p.rowdot = top;
     panel_launch_t<19, true>(p, st); }, fl);
