@@ -59,13 +59,34 @@ const char* mms_error_string(int code);
  *       one-word geometry (SimCross and the fused triplet step) and by the tiled
  *       word-grid backward; every other kernel always runs the reference mode.
  *   MMS_EUCLID_BWD_REFERENCE: the reference's bits, everywhere.
- * Process-wide; may also be chosen with the environment variable
- * MMS_EUCLID_BWD=reference|fp32 read at the first Euclidean launch.
+ * The mode belongs to the CALLING THREAD (a Caffe host drives each GPU from its own thread, and so does its
+ * `Caffe` singleton, src/caffe/common.cpp:13-15): mms_set_euclid_backward_mode changes it for the calling
+ * thread only and is read when a call is issued.  A thread that never set it uses the process default, the
+ * environment variable MMS_EUCLID_BWD=reference|fp32 (fp32 when unset).  The Layer mirror can pin a mode per
+ * layer (include/mms_layer.h: mms_layer_set_euclid_backward_mode).
  * ------------------------------------------------------------------------- */
 #define MMS_EUCLID_BWD_FP32 0
 #define MMS_EUCLID_BWD_REFERENCE 1
 int mms_set_euclid_backward_mode(int mode);
 int mms_get_euclid_backward_mode(void);
+
+/* Which comparison gates the hinge term in the PairRankLoss BACKWARD (the standalone entry point and the
+ * fused triplet step).  The reference's two implementations disagree where margin - y*(a-b) is exactly 0:
+ *   MMS_PAIRRANK_HINGE_CPU (default): `ordered > 0`,  PairRankLossLayer::Backward_cpu
+ *                                     (src/caffe/layers/pair_rank_loss_layer.cpp:76) -- the parity target;
+ *   MMS_PAIRRANK_HINGE_GPU:           `ordered >= 0`, the PairRankLossBackward kernel that Backward_gpu
+ *                                     launches (src/caffe/layers/pair_rank_loss_layer.cu:51).
+ * Set per calling thread, like the Euclidean mode above. */
+/* out[0] = sum_i x[i]*y[i], all three on the device (one workgroup, fixed summation tree).  The Layer mirror's
+ * Forward uses it for loss tops in GPU mode where the reference calls caffe_gpu_dot
+ * (include/caffe/layer.hpp:469-481, src/caffe/util/math_functions.cu caffe_gpu_dot). */
+int mms_dot_f32(int n, const float* x, const float* y, float* out, void* stream);
+int mms_dot_f64(int n, const double* x, const double* y, double* out, void* stream);
+
+#define MMS_PAIRRANK_HINGE_CPU 0
+#define MMS_PAIRRANK_HINGE_GPU 1
+int mms_set_pairrank_hinge_mode(int mode);
+int mms_get_pairrank_hinge_mode(void);
 
 /* ------------------------------------------------------------------------- *
  * SimCross  (q (N,W1,D), a (N,W2,D) -> top (N, M|1, W1, W2))
@@ -201,7 +222,7 @@ int mms_pairrank_backward_f32(int count, float top_diff, const float* y,
 size_t mms_pairrank_workspace_bytes(int count);
 
 /* ------------------------------------------------------------------------- *
- * Fused training step of the metric-learning inner loop (one launch):
+ * Fused training step of the metric-learning inner loop (one launch + a loss-finish launch, see below):
  *   s_pos = SimCross_euclid(q, a_pos), s_neg = SimCross_euclid(q, a_neg)   (N,1,1,1)
  *   loss  = PairRankLoss(s_pos, s_neg, y)                 (margin, loss_weight)
  *   backward through PairRankLoss and both SimCross layers:
@@ -211,6 +232,15 @@ size_t mms_pairrank_workspace_bytes(int count);
  * Outputs equal the layer-by-layer result (loss to 1e-5, the rest bitwise).
  * loss_partials: mms_triplet_workspace_bytes(N) bytes of device scratch.
  * ------------------------------------------------------------------------- */
+/* How the loss scalar of the fused step is summed (per calling thread):
+ *   MMS_TRIPLET_FINISH_LAUNCH (default): a second, one-workgroup launch adds the N per-triplet terms;
+ *   MMS_TRIPLET_FINISH_INLAUNCH: the step is ONE launch -- its last workgroup (two-level arrival tickets) adds
+ *       them.  Same results; measured slower on MI355X (12.6 vs 11.3 us at 4096 x 300), kept for hosts where a
+ *       launch costs more than it does under a hipGraph. */
+#define MMS_TRIPLET_FINISH_LAUNCH 0
+#define MMS_TRIPLET_FINISH_INLAUNCH 1
+int mms_set_triplet_finish_mode(int mode);
+int mms_get_triplet_finish_mode(void);
 int mms_triplet_euclid_step_f32(int N, int D, float margin, float loss_weight,
                                 const float* q, const float* a_pos,
                                 const float* a_neg, const float* y,

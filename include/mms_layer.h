@@ -53,6 +53,13 @@ void mms_layer_backward(mms_layer_t* l, mms_blob_t* const* top, int ntop,
 int mms_layer_num_param_blobs(mms_layer_t* l);
 mms_blob_t* mms_layer_param_blob(mms_layer_t* l, int i); /* borrowed; do not destroy */
 void mms_layer_set_param_propagate_down(mms_layer_t* l, int i, int v);
+/* Per-layer switches of THIS implementation (the reference's Layer has none).  Returns 0, or 1 for a key the
+ * layer does not know.
+ *   SimCross  "euclid_backward_mode": MMS_EUCLID_BWD_FP32 (0) / MMS_EUCLID_BWD_REFERENCE (1) for this layer's
+ *             Backward; -1 (default) = the calling thread's mode (include/mms.h).
+ *   SimMatrix "private_qw": 1 keeps the forward's Q*W in a blob of the layer; 0 (default) leaves it in
+ *             bottom[1]'s diff like the reference (sim_matrix_layer.cpp:58) and Backward scales it there. */
+int mms_layer_set_option(mms_layer_t* l, const char* key, int value);
 
 /* Caffe::set_mode (include/caffe/common.hpp): 0 = CPU, 1 = GPU (default).
  * This library is GPU-only: Forward/Backward in CPU mode is a fatal error. */

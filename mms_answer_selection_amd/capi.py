@@ -49,6 +49,12 @@ _SIGNATURES = {
     "mms_pairrank_backward_f64": (_i, [_i, C.c_double] + [_vp] * 3 + [_i, _i] + [_vp] * 3),
     "mms_set_euclid_backward_mode": (_i, [_i]),
     "mms_get_euclid_backward_mode": (_i, []),
+    "mms_dot_f32": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "mms_dot_f64": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "mms_set_triplet_finish_mode": (_i, [_i]),
+    "mms_get_triplet_finish_mode": (_i, []),
+    "mms_set_pairrank_hinge_mode": (_i, [_i]),
+    "mms_get_pairrank_hinge_mode": (_i, []),
     "mms_rank_workspace_bytes": (_sz, [_i]),
     "mms_rank_map_mrr_f32": (_i, [_i, _i] + [_vp] * 7 + [_sz, _vp]),
     "mms_rank_auc_f32": (_i, [_i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
@@ -313,6 +319,23 @@ def set_euclid_backward_mode(mode):
     """'fp32' (default: <= 2 ulp from the reference) or 'reference' (the reference's bits)."""
     m = {"fp32": 0, "reference": 1}.get(mode, mode)
     check(lib().mms_set_euclid_backward_mode(int(m)), "mms_set_euclid_backward_mode")
+
+
+def set_pairrank_hinge_mode(mode):
+    """'cpu' (default): `ordered > 0` as PairRankLossLayer::Backward_cpu; 'gpu': `ordered >= 0` as the
+    reference's .cu kernel.  Per calling thread."""
+    m = {"cpu": 0, "gpu": 1}[mode] if isinstance(mode, str) else int(mode)
+    check(lib().mms_set_pairrank_hinge_mode(m), "mms_set_pairrank_hinge_mode")
+
+
+def set_triplet_finish_mode(mode):
+    """'launch' (default): second launch sums the loss terms; 'inlaunch': the step's last workgroup does."""
+    m = {"launch": 0, "inlaunch": 1}[mode] if isinstance(mode, str) else int(mode)
+    check(lib().mms_set_triplet_finish_mode(m), "mms_set_triplet_finish_mode")
+
+
+def get_pairrank_hinge_mode():
+    return "gpu" if lib().mms_get_pairrank_hinge_mode() == 1 else "cpu"
 
 
 def get_euclid_backward_mode():

@@ -343,6 +343,10 @@ template <typename Dtype>
 Filler<Dtype>* GetFiller(const FillerParameter& param);
 
 // ------------------------------------- Layer ---------------------------------
+// include/caffe/util/math_functions.hpp:152 (caffe_gpu_dot): x . y on the device, result on the host
+float caffe_gpu_dot(int n, const float* x, const float* y);
+double caffe_gpu_dot(int n, const double* x, const double* y);
+
 template <typename Dtype>
 class Layer {
  public:
@@ -385,6 +389,9 @@ class Layer {
     if ((int)param_propagate_down_.size() <= id) param_propagate_down_.resize(id + 1, true);
     param_propagate_down_[id] = v;
   }
+  // NOT in the reference's Layer: per-layer switches of this implementation (include/mms_layer.h:
+  // mms_layer_set_option).  Returns false for a key the layer does not know.
+  virtual bool SetOption(const std::string& key, int value) { return false; }
 
  protected:
   LayerParameter layer_param_;
@@ -443,14 +450,19 @@ inline Dtype Layer<Dtype>::Forward(const vector<Blob<Dtype>*>& bottom, const vec
       Forward_gpu(bottom, top);
       break;
   }
-  // loss = sum_top dot(top.data, top.diff) for tops that carry a loss weight
+  // loss = sum_top dot(top.data, top.diff) for tops that carry a loss weight (layer.hpp:462-481: a host loop
+  // in CPU mode, caffe_gpu_dot on the device in GPU mode -- the blob's head does not move to the host)
   for (size_t top_id = 0; top_id < top.size(); ++top_id) {
     if (!this->loss((int)top_id)) continue;
     const int count = top[top_id]->count();
-    const Dtype* data = top[top_id]->cpu_data();
-    const Dtype* loss_weights = top[top_id]->cpu_diff();
     Dtype blob_loss = 0;
-    for (int i = 0; i < count; ++i) blob_loss += data[i] * loss_weights[i];
+    if (Caffe::mode() == Caffe::GPU) {
+      blob_loss = caffe_gpu_dot(count, top[top_id]->gpu_data(), top[top_id]->gpu_diff());
+    } else {
+      const Dtype* data = top[top_id]->cpu_data();
+      const Dtype* loss_weights = top[top_id]->cpu_diff();
+      for (int i = 0; i < count; ++i) blob_loss += data[i] * loss_weights[i];
+    }
     loss += blob_loss;
   }
   return loss;

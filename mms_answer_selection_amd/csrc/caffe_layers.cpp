@@ -88,6 +88,19 @@ template Filler<double>* GetFiller<double>(const FillerParameter&);
 static void mms_check(int rc, const char* what) {
   CHECK_EQ(rc, (int)MMS_OK) << what << ": " << mms_error_string(rc);
 }
+
+// caffe_gpu_dot (src/caffe/util/math_functions.cu): the product is formed on the device, one scalar comes back
+template <typename T, typename F>
+static T gpu_dot_impl(int n, const T* x, const T* y, F fn) {
+  static thread_local T* dev = nullptr;
+  if (!dev && hipMalloc(reinterpret_cast<void**>(&dev), sizeof(T)) != hipSuccess) MMS_FATAL("") << "hipMalloc failed";
+  mms_check(fn(n, x, y, dev, nullptr), "mms_dot");
+  T host = 0;
+  if (hipMemcpy(&host, dev, sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) MMS_FATAL("") << "hipMemcpy failed";
+  return host;
+}
+float caffe_gpu_dot(int n, const float* x, const float* y) { return gpu_dot_impl<float>(n, x, y, mms_dot_f32); }
+double caffe_gpu_dot(int n, const double* x, const double* y) { return gpu_dot_impl<double>(n, x, y, mms_dot_f64); }
 // The C ABI by element type: what lets one layer template serve Layer<float> and Layer<double>.
 namespace abi {
 inline size_t simcross_ws(float, int mode, int N, int W1, int W2, int D, int M) { return mms_simcross_workspace_bytes(mode, N, W1, W2, D, M); }
@@ -206,6 +219,13 @@ class SimCrossLayer : public Layer<Dtype> {
     if (ws) workspace_.Reshape(vector<int>{(int)((ws + sizeof(Dtype) - 1) / sizeof(Dtype))});
   }
 
+  // "euclid_backward_mode": MMS_EUCLID_BWD_FP32 (0) / MMS_EUCLID_BWD_REFERENCE (1) for THIS layer; -1 = the thread's
+  bool SetOption(const std::string& key, int value) override {
+    if (key != "euclid_backward_mode" || value < -1 || value > 1) return false;
+    euclid_bwd_mode_ = value;
+    return true;
+  }
+
  protected:
   void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
   void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
@@ -232,6 +252,15 @@ class SimCrossLayer : public Layer<Dtype> {
     const int M = top[0]->channels();
     const bool mode2 = dist_mode_ == 2, mode0 = dist_mode_ == 0;
     const bool bias_term = mode2 && this->blobs_.size() > 1;
+    // this layer's arithmetic of the Euclidean backward term, if one was pinned (SetOption): the C ABI's mode
+    // belongs to the calling thread, so it is set for the duration of this call and put back
+    struct ModeGuard {
+      int saved;
+      explicit ModeGuard(int m) : saved(-1) {
+        if (m >= 0) { saved = mms_get_euclid_backward_mode(); mms_set_euclid_backward_mode(m); }
+      }
+      ~ModeGuard() { if (saved >= 0) mms_set_euclid_backward_mode(saved); }
+    } guard(euclid_bwd_mode_);
     mms_check(abi::simcross_backward(
                   dist_mode_, bottom[0]->num(), bottom[0]->channels(), bottom[1]->channels(),
                   bottom[0]->height(), M, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
@@ -247,6 +276,7 @@ class SimCrossLayer : public Layer<Dtype> {
   }
 
   int dist_mode_ = 1;  // 1 euclid, 0 cosine, 2 bilinear (sim_cross_layer.hpp:36)
+  int euclid_bwd_mode_ = -1;  // -1: the calling thread's mode; else MMS_EUCLID_BWD_FP32 / _REFERENCE for this layer
   Blob<Dtype> data0_norm_, data1_norm_;
   Blob<Dtype> workspace_;  // replaces measure_temp{0,1}_
 };
@@ -287,23 +317,25 @@ class SimMatrixLayer : public Layer<Dtype> {
     top[0]->Reshape(vector<int>{bottom[0]->shape(0), 1});
     const size_t ws = abi::simmatrix_ws(Dtype(0), M_, K1_, K2_);
     workspace_.Reshape(vector<int>{(int)((ws + sizeof(Dtype) - 1) / sizeof(Dtype))});
-    if (qw_.count() != M_ * K2_) qw_valid_ = false;
-    qw_.Reshape(vector<int>{M_, K2_});
+    if (qw_elems_ != M_ * K2_) { qw_valid_ = false; qw_elems_ = M_ * K2_; }
+    if (private_qw_) qw_.Reshape(vector<int>{M_, K2_});
   }
 
  protected:
   void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
   void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) override { NO_CPU_MODE; }
 
-  // replaces sim_matrix_layer.cpp:53-65.  The reference parks Q*W in bottom[1]'s diff (:58) and
-  // recomputes W^T q_j per pair in Backward (:88); here the product is kept in a member blob --
-  // like SimCross's cached norms (sim_cross_layer.hpp:40-41) -- so that Backward scales it into
-  // bottom[1]'s diff instead of running the same GEMM again, whatever a caller did to that diff
-  // in between.
+  // replaces sim_matrix_layer.cpp:53-65.  Like the reference, Forward leaves Q*W in bottom[1]'s DIFF buffer
+  // (:58 takes bottom[1]->mutable_cpu_diff() as its scratch) -- an observable side effect, kept by default.
+  // Backward then finds the product where the reference's forward left it and scales it in place into
+  // da_j = dT_j * (W^T q_j) (:88) instead of running the same GEMM again: nothing in a Caffe net writes a
+  // bottom's diff between a layer's Forward and its own Backward.  A host that does touch that buffer in
+  // between can switch the layer to a private copy: SetOption("private_qw", 1) (then Forward leaves
+  // bottom[1]'s diff alone, which is the only difference).
   void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
+    Dtype* qw = private_qw_ ? qw_.mutable_gpu_data() : bottom[1]->mutable_gpu_diff();
     mms_check(abi::simmatrix_forward(M_, K1_, K2_, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
-                                     this->blobs_[0]->gpu_data(), top[0]->mutable_gpu_data(),
-                                     qw_.mutable_gpu_data()),
+                                     this->blobs_[0]->gpu_data(), top[0]->mutable_gpu_data(), qw),
               "mms_simmatrix_forward");
     qw_valid_ = true;
   }
@@ -312,15 +344,17 @@ class SimMatrixLayer : public Layer<Dtype> {
                     const vector<Blob<Dtype>*>& bottom) override {
     const bool ppd = this->param_propagate_down_[0];
     if (qw_valid_) {
+      const Dtype* qw = private_qw_ ? qw_.gpu_data() : bottom[1]->gpu_diff();   // in place when it is the diff
       mms_check(abi::simmatrix_backward_cached(
                     M_, K1_, K2_, bottom[0]->gpu_data(), bottom[1]->gpu_data(), this->blobs_[0]->gpu_data(),
-                    qw_.gpu_data(), top[0]->gpu_diff(), ppd, propagate_down[0], propagate_down[1],
+                    qw, top[0]->gpu_diff(), ppd, propagate_down[0], propagate_down[1],
                     propagate_down[0] ? bottom[0]->mutable_gpu_diff() : nullptr,
                     propagate_down[1] ? bottom[1]->mutable_gpu_diff() : nullptr,
                     ppd ? this->blobs_[0]->mutable_gpu_diff() : nullptr,
                     workspace_.count() ? workspace_.mutable_gpu_data() : nullptr,
                     (size_t)workspace_.count() * sizeof(Dtype)),
                 "mms_simmatrix_backward_cached");
+      if (!private_qw_ && propagate_down[1]) qw_valid_ = false;   // the diff now holds da, not Q*W
       return;
     }
     mms_check(abi::simmatrix_backward(
@@ -333,10 +367,20 @@ class SimMatrixLayer : public Layer<Dtype> {
                   (size_t)workspace_.count() * sizeof(Dtype)),
               "mms_simmatrix_backward");
   }
+ public:
+  bool SetOption(const std::string& key, int value) override {
+    if (key != "private_qw") return false;
+    private_qw_ = value != 0;
+    qw_valid_ = false;
+    return true;
+  }
+ protected:
   int K1_ = 0, K2_ = 0, M_ = 0;
   Blob<Dtype> workspace_;
-  Blob<Dtype> qw_;             // Q*W of the last Forward (M_, K2_)
+  Blob<Dtype> qw_;             // private_qw: Q*W of the last Forward (M_, K2_)
   bool qw_valid_ = false;
+  bool private_qw_ = false;
+  int qw_elems_ = 0;
 };
 INSTANTIATE_CLASS_FD(SimMatrixLayer);
 REGISTER_LAYER_CLASS_FD(SimMatrix);
@@ -1162,6 +1206,7 @@ mms_blob_t* mms_layer_param_blob(mms_layer_t* l, int i) {
   return l->param_handles[i].get();
 }
 void mms_layer_set_param_propagate_down(mms_layer_t* l, int i, int v) { l->l->set_param_propagate_down(i, v != 0); }
+int mms_layer_set_option(mms_layer_t* l, const char* key, int value) { return (key && l->l->SetOption(key, value)) ? 0 : 1; }
 void mms_caffe_set_mode(int gpu) { caffe::Caffe::set_mode(gpu ? caffe::Caffe::GPU : caffe::Caffe::CPU); }
 void mms_caffe_set_random_seed(unsigned seed) { caffe::caffe_set_random_seed(seed); }
 const char* mms_layer_registry_types(void) {

@@ -63,6 +63,10 @@ int embed_backward(int M, int N, int K, const float* index, const float* top_dif
                    float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes, hipStream_t s);
 int euclid_backward_mode();
 void set_euclid_backward_mode(int m);
+int pairrank_hinge_mode();
+void set_pairrank_hinge_mode(int m);
+int triplet_finish_mode();
+void set_triplet_finish_mode(int m);
 // f64_paths.hip
 size_t simcross_workspace_bytes_f64(int mode, int N, int W1, int W2, int D, int M);
 int simcross_forward_f64(int mode, int N, int W1, int W2, int D, int M, const double* q, const double* a,
@@ -101,6 +105,25 @@ bool dims_ok(int mode, int N, int W1, int W2, int D, int M) {
 }
 hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 }  // namespace
+
+// x . y with the result left on the device (fixed-shape tree: deterministic); what Layer::Forward needs for a
+// loss top in GPU mode (include/caffe/layer.hpp:469-481 calls caffe_gpu_dot there)
+namespace mms {
+template <typename T>
+__global__ __launch_bounds__(256) void dot_kernel(int n, const T* __restrict__ x, const T* __restrict__ y,
+                                                  T* __restrict__ out) {
+  __shared__ T red[256];
+  T s = 0;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i] * y[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = red[0];
+}
+}  // namespace mms
 
 extern "C" {
 
@@ -365,6 +388,30 @@ int mms_set_euclid_backward_mode(int mode) {
   return MMS_OK;
 }
 int mms_get_euclid_backward_mode(void) { return euclid_backward_mode(); }
+
+int mms_dot_f32(int n, const float* x, const float* y, float* out, void* stream) {
+  if (n < 0 || !out || (n > 0 && (!x || !y))) return MMS_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(mms::dot_kernel<float>, dim3(1), dim3(256), 0, as_stream(stream), n, x, y, out);
+  return launch_status();
+}
+int mms_dot_f64(int n, const double* x, const double* y, double* out, void* stream) {
+  if (n < 0 || !out || (n > 0 && (!x || !y))) return MMS_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(mms::dot_kernel<double>, dim3(1), dim3(256), 0, as_stream(stream), n, x, y, out);
+  return launch_status();
+}
+
+int mms_set_pairrank_hinge_mode(int mode) {
+  if (mode != MMS_PAIRRANK_HINGE_CPU && mode != MMS_PAIRRANK_HINGE_GPU) return MMS_ERR_INVALID_ARG;
+  set_pairrank_hinge_mode(mode);
+  return MMS_OK;
+}
+int mms_get_pairrank_hinge_mode(void) { return pairrank_hinge_mode(); }
+int mms_set_triplet_finish_mode(int mode) {
+  if (mode != MMS_TRIPLET_FINISH_LAUNCH && mode != MMS_TRIPLET_FINISH_INLAUNCH) return MMS_ERR_INVALID_ARG;
+  set_triplet_finish_mode(mode);
+  return MMS_OK;
+}
+int mms_get_triplet_finish_mode(void) { return triplet_finish_mode(); }
 
 // ---- double instantiation (csrc/f64_paths.hip): same contracts as the _f32 entry points ----
 size_t mms_simcross_workspace_bytes_f64(int dist_mode, int N, int W1, int W2, int D, int M) {

@@ -10,12 +10,31 @@
 // Per-element values are bit-identical to the CPU code.  The loss scalar is a
 // fixed-shape tree sum (deterministic; the reference's 1-thread running sum
 // is not reproduced -- tests hold it to 1e-5 relative).
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
 #include "euclid_math.h"
 #include "mms_common.h"
 
 namespace mms {
 
 int euclid_backward_mode();   // simcross_elementwise.hip
+
+// Which comparison gates the hinge term of the backward (include/mms.h: mms_set_pairrank_hinge_mode):
+// the reference's Backward_cpu uses `ordered > 0` (pair_rank_loss_layer.cpp:76), its Backward_gpu kernel
+// `ordered >= 0` (pair_rank_loss_layer.cu:51).  They differ only where margin - y*(a-b) is exactly 0.
+// Per calling thread (a Caffe host runs one thread per GPU); default: the CPU code's strict `>`.
+constexpr int kTicketSlots = 256;
+constexpr int kTicketTop = 1024;      // words 0..1023 of a ticket slot: one per group of 8 workgroups; then the top word
+constexpr int kTicketStride = kTicketTop + 32;
+
+static thread_local int t_hinge_mode = MMS_PAIRRANK_HINGE_CPU;
+int pairrank_hinge_mode() { return t_hinge_mode; }
+void set_pairrank_hinge_mode(int m) { t_hinge_mode = m; }
+static thread_local int t_triplet_finish = MMS_TRIPLET_FINISH_LAUNCH;
+int triplet_finish_mode() { return t_triplet_finish; }
+void set_triplet_finish_mode(int m) { t_triplet_finish = m; }
 
 struct PairTerm {
   float ordered, similar, term;
@@ -37,8 +56,8 @@ __device__ __forceinline__ PairTerm pair_term(float a, float b, float y, float m
 
 // :72-79 for one element; s0/s1 are the two `sign` values.
 __device__ __forceinline__ void pair_grad(float y, float ordered, float similar, float s0,
-                                          float s1, float& ga, float& gb) {
-  const float ordered_t = ordered > 0.0f ? 1.0f : 0.0f;
+                                          float s1, float& ga, float& gb, bool ge = false) {
+  const float ordered_t = (ge ? ordered >= 0.0f : ordered > 0.0f) ? 1.0f : 0.0f;
   const float similar_t = (1.0f - y) * similar > 0.0f ? 1.0f : -1.0f;
   const float inner = ordered_t * y - similar_t * (1.0f - y);
   ga = s0 * inner;
@@ -93,11 +112,11 @@ __global__ __launch_bounds__(kPairThreads) void loss_finish_kernel(
 __global__ __launch_bounds__(256) void pairrank_bwd_kernel(
     int count, float s0, float s1, const float* __restrict__ y,
     const float* __restrict__ ordered, const float* __restrict__ similar,
-    float* __restrict__ da, float* __restrict__ db) {
+    float* __restrict__ da, float* __restrict__ db, int hinge_ge) {
   const int stride = gridDim.x * 256;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
     float ga, gb;
-    pair_grad(y[i], ordered[i], similar[i], s0, s1, ga, gb);
+    pair_grad(y[i], ordered[i], similar[i], s0, s1, ga, gb, hinge_ge != 0);
     if (da) da[i] = ga;
     if (db) db[i] = gb;
   }
@@ -174,7 +193,7 @@ int pairrank_backward(int count, float top_diff, const float* y, const float* or
   int blocks = (count + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(pairrank_bwd_kernel, dim3(blocks), dim3(256), 0, s, count, s0, s1, y,
-                     ordered, similar, da, db);
+                     ordered, similar, da, db, pairrank_hinge_mode() == MMS_PAIRRANK_HINGE_GPU ? 1 : 0);
   return launch_status();
 }
 
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(256) void triplet_wave_kernel(
     int N, int D4, float margin, float s0, float s1, const float* __restrict__ q,
     const float* __restrict__ ap, const float* __restrict__ an, const float* __restrict__ y,
     float* __restrict__ s_pos, float* __restrict__ s_neg, float* __restrict__ partials,
-    float* __restrict__ dq, float* __restrict__ dap, float* __restrict__ dan) {
+    float* __restrict__ dq, float* __restrict__ dap, float* __restrict__ dan, int hinge_ge) {
   extern __shared__ float4 lds4[];               // [4 waves][2 branches] split images (euclid_math.h)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave;
@@ -261,7 +280,7 @@ __global__ __launch_bounds__(256) void triplet_wave_kernel(
   // PairRankLoss on (Tp, Tn, y): every lane computes the same scalars
   const PairTerm pt = pair_term(Tp, Tn, yy, margin);
   float ga, gb;
-  pair_grad(yy, pt.ordered, pt.similar, s0, s1, ga, gb);
+  pair_grad(yy, pt.ordered, pt.similar, s0, s1, ga, gb, hinge_ge != 0);
   if (lane == 0) partials[row] = pt.term;
   const EuclidCoef k0 = euclid_coef(Tp, ga), k1 = euclid_coef(Tn, gb);
 
@@ -299,7 +318,8 @@ __global__ __launch_bounds__(64 * WPB) void triplet32_kernel(
     int N, float margin, float s0, float s1, const float* __restrict__ q,
     const float* __restrict__ ap, const float* __restrict__ an, const float* __restrict__ y,
     float* __restrict__ s_pos, float* __restrict__ s_neg, float* __restrict__ partials,
-    float* __restrict__ dq, float* __restrict__ dap, float* __restrict__ dan) {
+    float* __restrict__ dq, float* __restrict__ dap, float* __restrict__ dan, int hinge_ge,
+    unsigned* __restrict__ ticket, float* __restrict__ loss) {
   constexpr int NIT = (D4C + 63) / 64;
   constexpr int LASTN = D4C - 64 * (NIT - 1);
   constexpr int H4 = (D4C + 2) / 3, ST4 = 3 * H4;
@@ -372,9 +392,10 @@ __global__ __launch_bounds__(64 * WPB) void triplet32_kernel(
   // PairRankLoss on (Tp, Tn, y): every lane computes the same scalars
   const PairTerm pt = pair_term(Tp, Tn, yy, margin);
   float ga, gb;
-  pair_grad(yy, pt.ordered, pt.similar, s0, s1, ga, gb);
-  if (lane == 0 && have) partials[row] = pt.term;
-  if (!have) return;
+  pair_grad(yy, pt.ordered, pt.similar, s0, s1, ga, gb, hinge_ge != 0);
+  // the loss term leaves as a write-through (sc1) store: the launch's last workgroup sums all N of them
+  if (lane == 0 && have) __hip_atomic_store(&partials[row], pt.term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" ::: "memory");                   // stays ahead of the streaming stores below (counted wait at the end)
 
   float4* dq4 = reinterpret_cast<float4*>(dq) + base4;
   float4* dp4 = reinterpret_cast<float4*>(dap) + base4;
@@ -396,18 +417,65 @@ __global__ __launch_bounds__(64 * WPB) void triplet32_kernel(
       tn[it].z = (c1 * dn[it].z) * r1; tn[it].w = (c1 * dn[it].w) * r1;
     }
   }
+  if (have) {
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    if (!((it < NIT - 1) || last_ok)) break;
-    const int i = lane + 64 * it;
-    float4 oq, op, on;
-    oq.x = (0.f + tp[it].x) + (0.f + tn[it].x); oq.y = (0.f + tp[it].y) + (0.f + tn[it].y);
-    oq.z = (0.f + tp[it].z) + (0.f + tn[it].z); oq.w = (0.f + tp[it].w) + (0.f + tn[it].w);
-    op.x = 0.f + (-tp[it].x); op.y = 0.f + (-tp[it].y); op.z = 0.f + (-tp[it].z); op.w = 0.f + (-tp[it].w);
-    on.x = 0.f + (-tn[it].x); on.y = 0.f + (-tn[it].y); on.z = 0.f + (-tn[it].z); on.w = 0.f + (-tn[it].w);
-    stream_store(dq4 + i, oq);
-    stream_store(dp4 + i, op);
-    stream_store(dn4 + i, on);
+    for (int it = 0; it < NIT; ++it) {
+      if (!((it < NIT - 1) || last_ok)) break;
+      const int i = lane + 64 * it;
+      float4 oq, op, on;
+      oq.x = (0.f + tp[it].x) + (0.f + tn[it].x); oq.y = (0.f + tp[it].y) + (0.f + tn[it].y);
+      oq.z = (0.f + tp[it].z) + (0.f + tn[it].z); oq.w = (0.f + tp[it].w) + (0.f + tn[it].w);
+      op.x = 0.f + (-tp[it].x); op.y = 0.f + (-tp[it].y); op.z = 0.f + (-tp[it].z); op.w = 0.f + (-tp[it].w);
+      on.x = 0.f + (-tn[it].x); on.y = 0.f + (-tn[it].y); on.z = 0.f + (-tn[it].z); on.w = 0.f + (-tn[it].w);
+      stream_store(dq4 + i, oq);
+      stream_store(dp4 + i, op);
+      stream_store(dn4 + i, on);
+    }
+  }
+
+  // ---- loss scalar in the same launch (this used to be a second, one-workgroup launch: 2.3 us) -----------
+  // Hand-off of MI355X_MICROARCH.md "Valid forms": write-through term stores -> every storing wave drains its
+  // stores -> workgroup barrier -> ONE agent-scope ticket per workgroup; the workgroup whose ticket is the
+  // last reads every term with sc1 loads (never through L1) and sums them in a fixed order.
+  // only the TERM store has to be complete before the ticket: it was issued ahead of this wave's 3 * NIT
+  // streaming stores, which may still be in flight
+  if (ticket == nullptr) return;                   // the caller sums the terms with a second launch
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NIT) : "memory");
+  __shared__ unsigned last_flag;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // two-level arrival (all workgroups finish together: 512 adds on ONE word serialise to ~6 us): groups of 8
+    // workgroups share a word, the last of a group adds to the top word
+    const unsigned grp = blockIdx.x >> 3, ngrp = (gridDim.x + 7) >> 3;
+    const unsigned gsize = min(8u, gridDim.x - 8u * grp);
+    unsigned last = 0;
+    if (__hip_atomic_fetch_add(ticket + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+      __hip_atomic_store(ticket + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = __hip_atomic_fetch_add(ticket + kTicketTop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1;
+    }
+    last_flag = last;
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  {
+    constexpr int TH = 64 * WPB;
+    float* red = reinterpret_cast<float*>(lds4);   // the chain images are dead
+    float sum = 0.f;
+    for (int base = threadIdx.x; base < N; base += 8 * TH) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * TH;
+        v[u] = __hip_atomic_load(&partials[i < N ? i : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += (base + u * TH < N) ? v[u] : 0.f;
+    }
+    sum = block_sum<TH>(sum, red);
+    if (threadIdx.x == 0) {
+      *loss = sum / (float)N;                     // pair_rank_loss_layer.cpp:49
+      __hip_atomic_store(ticket + kTicketTop, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
   }
 }
 
@@ -417,7 +485,7 @@ __global__ __launch_bounds__(THREADS) void triplet_generic_kernel(
     int N, int D, float margin, float s0, float s1, const float* __restrict__ q,
     const float* __restrict__ ap, const float* __restrict__ an, const float* __restrict__ y,
     float* __restrict__ s_pos, float* __restrict__ s_neg, float* __restrict__ partials,
-    float* __restrict__ dq, float* __restrict__ dap, float* __restrict__ dan) {
+    float* __restrict__ dq, float* __restrict__ dap, float* __restrict__ dan, int hinge_ge) {
   extern __shared__ float4 lds_raw[];
   float* dpos = reinterpret_cast<float*>(lds_raw);   // [ROWS*D]
   float* dneg = dpos + (size_t)ROWS * D;             // [ROWS*D]
@@ -455,7 +523,7 @@ __global__ __launch_bounds__(THREADS) void triplet_generic_kernel(
       const float yy = y[row0 + r];
       const PairTerm p = pair_term(Ts[0][r], Ts[1][r], yy, margin);
       float ga, gb;
-      pair_grad(yy, p.ordered, p.similar, s0, s1, ga, gb);
+      pair_grad(yy, p.ordered, p.similar, s0, s1, ga, gb, hinge_ge != 0);
       const EuclidCoef k0 = euclid_coef(Ts[0][r], ga), k1 = euclid_coef(Ts[1][r], gb);
       cs[0][r] = k0.c; dens[0][r] = k0.den;
       cs[1][r] = k1.c; dens[1][r] = k1.den;
@@ -484,6 +552,26 @@ __global__ __launch_bounds__(THREADS) void triplet_generic_kernel(
 constexpr int kTripRows = 8;
 constexpr int kTripThreads = 256;
 
+// Arrival tickets of the in-launch loss reduction.  A slot is zero when no launch is using it (module load
+// zeroes them; the launch's last workgroup resets its slot), and consecutive calls take consecutive slots, so
+// launches in flight together -- other streams, other captured graphs -- never share one (a slot comes round
+// again after kTicketSlots calls).
+__device__ unsigned g_triplet_tickets[kTicketSlots * kTicketStride];
+static unsigned* next_ticket_slot() {
+  static std::atomic<unsigned> next{0};
+  static thread_local unsigned* base = nullptr;    // device address of the array on this thread's current device
+  static thread_local int base_dev = -1;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (base == nullptr || dev != base_dev) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_triplet_tickets)) != hipSuccess) return nullptr;
+    base = static_cast<unsigned*>(p);
+    base_dev = dev;
+  }
+  return base + (size_t)(next.fetch_add(1, std::memory_order_relaxed) % kTicketSlots) * kTicketStride;
+}
+
 // one float per triplet (wave kernel) -- the generic kernel needs fewer
 size_t triplet_workspace_bytes(int N) { return (size_t)N * sizeof(float); }
 
@@ -496,6 +584,7 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
   const float scale = loss_weight / (float)N;  // pair_rank_loss_layer.cpp:64, count = N*1
   const float s0 = -1.0f * scale, s1 = 1.0f * scale;
   float* partials = static_cast<float*>(ws);
+  const int hge = pairrank_hinge_mode() == MMS_PAIRRANK_HINGE_GPU ? 1 : 0;
   const bool v = (D % 4 == 0) && aligned16(q) && aligned16(ap) && aligned16(an) &&
                  aligned16(dq) && aligned16(dap) && aligned16(dan);
   int nparts;
@@ -508,13 +597,22 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
   case 4 * d4:                                                                                    \
     if (exact)                                                                                    \
       hipLaunchKernelGGL((triplet32_kernel<d4, true, WPB>), dim3(grid), dim3(64 * WPB), 0, s, N,  \
-                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan);     \
+                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan, hge, \
+                         tk, loss);                                                               \
     else                                                                                          \
       hipLaunchKernelGGL((triplet32_kernel<d4, false, WPB>), dim3(grid), dim3(64 * WPB), 0, s, N, \
-                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan);     \
+                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan, hge, \
+                         tk, loss);                                                               \
     break;
+    // Default: the loss terms are summed by a second, one-workgroup launch.  The in-launch form (last workgroup
+    // sums, mms_set_triplet_finish_mode) was built and measured SLOWER on MI355X: 12.6 vs 11.3 us per 4096 x 300
+    // step HBM-cold -- the write-through term store's acknowledgement, two ticket round trips and the 16 KB read
+    // of the terms form a serial tail of ~4 us behind the last store, the kernel boundary + finish launch 3.5.
+    unsigned* tk = (triplet_finish_mode() != MMS_TRIPLET_FINISH_INLAUNCH || (grid + 7) / 8 > (unsigned)kTicketTop)
+                       ? nullptr : next_ticket_slot();
     switch (D) { MMS_T32(25) MMS_T32(50) MMS_T32(75) }
 #undef MMS_T32
+    if (tk) return launch_status();               // the loss was reduced inside the launch
   } else if (v && D <= 1024) {
     const int D4 = D / 4;
     const int nit = (D4 + 63) / 64;
@@ -526,10 +624,10 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
   case n:                                                                                       \
     if (spec)                                                                                   \
       hipLaunchKernelGGL((triplet_wave_kernel<n, true>), dim3(grid), dim3(256), lds, s, N, D4,  \
-                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan);   \
+                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan, hge);   \
     else                                                                                        \
       hipLaunchKernelGGL((triplet_wave_kernel<n, false>), dim3(grid), dim3(256), lds, s, N, D4, \
-                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan);   \
+                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan, hge);   \
     break;
     switch (nit) { MMS_NIT_CASE(1) MMS_NIT_CASE(2) MMS_NIT_CASE(3) MMS_NIT_CASE(4) }
 #undef MMS_NIT_CASE
@@ -539,7 +637,7 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
     nparts = (N + kTripRows - 1) / kTripRows;
     hipLaunchKernelGGL((triplet_generic_kernel<kTripRows, kTripThreads>), dim3(nparts),
                        dim3(kTripThreads), lds, s, N, D, margin, s0, s1, q, ap, an, y, s_pos,
-                       s_neg, partials, dq, dap, dan);
+                       s_neg, partials, dq, dap, dan, hge);
   }
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kPairThreads), 0, s, partials, nparts, N,
                      loss);

@@ -1383,19 +1383,23 @@ static bool wave_ok(int D, const void* p0, const void* p1, const void* p2, const
   return vec4_ok(D, p0, p1, p2, p3) && D <= 1024;
 }
 
-// Backward arithmetic of the Euclidean term (include/mms.h: mms_set_euclid_backward_mode).
-static std::atomic<int> g_euclid_bwd_mode{-1};
+// Backward arithmetic of the Euclidean term (include/mms.h: mms_set_euclid_backward_mode).  The mode
+// belongs to the calling thread (Caffe drives each GPU from its own thread); a thread that never set it
+// takes the process default from the environment.
+static std::atomic<int> g_euclid_bwd_default{-1};
+static thread_local int t_euclid_bwd_mode = -1;
 int euclid_backward_mode() {
-  int m = g_euclid_bwd_mode.load(std::memory_order_relaxed);
+  if (t_euclid_bwd_mode >= 0) return t_euclid_bwd_mode;
+  int m = g_euclid_bwd_default.load(std::memory_order_relaxed);
   if (m < 0) {
     const char* e = std::getenv("MMS_EUCLID_BWD");
     m = (e && (!std::strcmp(e, "reference") || !std::strcmp(e, "exact") || !std::strcmp(e, "1")))
             ? MMS_EUCLID_BWD_REFERENCE : MMS_EUCLID_BWD_FP32;
-    g_euclid_bwd_mode.store(m, std::memory_order_relaxed);
+    g_euclid_bwd_default.store(m, std::memory_order_relaxed);
   }
   return m;
 }
-void set_euclid_backward_mode(int m) { g_euclid_bwd_mode.store(m, std::memory_order_relaxed); }
+void set_euclid_backward_mode(int m) { t_euclid_bwd_mode = m; }
 
 // widths with a specialised kernel: 100-d, 200-d and 300-d GloVe (D4 = 25, 50, 75)
 static bool pair32_width(int D) { return D == 300 || D == 200 || D == 100; }

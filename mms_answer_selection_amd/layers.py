@@ -42,6 +42,7 @@ _SIGNATURES = {
     "mms_layer_num_param_blobs": (_i, [_vp]),
     "mms_layer_param_blob": (_vp, [_vp, _i]),
     "mms_layer_set_param_propagate_down": (None, [_vp, _i, _i]),
+    "mms_layer_set_option": (_i, [_vp, C.c_char_p, _i]),
     "mms_caffe_set_mode": (None, [_i]),
     "mms_caffe_set_random_seed": (None, [C.c_uint]),
     "mms_layer_registry_types": (C.c_char_p, []),
@@ -232,6 +233,11 @@ class Layer:
 
     def set_param_propagate_down(self, i, v):
         lib().mms_layer_set_param_propagate_down(self._h, int(i), 1 if v else 0)
+
+    def set_option(self, key, value):
+        """Per-layer switch of this implementation (include/mms_layer.h: mms_layer_set_option)."""
+        if lib().mms_layer_set_option(self._h, key.encode(), int(value)) != 0:
+            raise KeyError("%s layer has no option %r" % (self.type, key))
 
 
 def _make(type_name, param_field, name=None, loss_weight=None, top=None, **kwargs):

@@ -495,6 +495,92 @@ def test_pairrank(cfg, oracle, hiplib):
     assert_bitexact(host(gb2), db_ref)
 
 
+def test_pairrank_hinge_comparison_modes(oracle, hiplib):
+    """Where margin - y*(a-b) is EXACTLY zero the reference's two backward implementations disagree:
+    Backward_cpu gates the hinge term with `ordered > 0` (pair_rank_loss_layer.cpp:76, the default here and the
+    oracle), the .cu kernel with `>= 0` (pair_rank_loss_layer.cu:51).  Both are selectable; they differ only there."""
+    from mms_answer_selection_amd import capi
+    N, margin = 64, 0.5
+    r = rng(77)
+    a = r.uniform(0, 1, (N, 1)).astype(np.float32)
+    b = r.uniform(0, 1, (N, 1)).astype(np.float32)
+    y = (r.uniform(size=(N, 1)) < 0.5).astype(np.float32)
+    a[:4, 0], b[:4, 0], y[:4, 0] = 0.75, 0.25, 1.0          # diff = margin, y = 1: ordered == 0 exactly
+    loss_ref, ord_ref, sim_ref = oracle.pairrank_forward(a, b, y, margin)
+    assert (ord_ref[:4] == 0).all()
+    da_ref, db_ref = oracle.pairrank_backward(y, ord_ref, sim_ref, top_diff=1.0)
+    o, s, loss = nan_like(a.shape), nan_like(a.shape), nan_like((1,))
+    capi.pairrank_forward(dev(a), dev(b), dev(y), o, s, loss, margin=margin)
+    ga, gb = nan_like(a.shape), nan_like(a.shape)
+    assert capi.get_pairrank_hinge_mode() == "cpu"
+    capi.pairrank_backward(dev(y), o, s, ga, gb)
+    assert_bitexact(host(ga), da_ref, "da, Backward_cpu comparison")
+    try:
+        capi.set_pairrank_hinge_mode("gpu")
+        capi.pairrank_backward(dev(y), o, s, ga, gb)
+    finally:
+        capi.set_pairrank_hinge_mode("cpu")
+    g = host(ga)
+    assert_bitexact(g[4:], da_ref[4:], "elements off the tie are untouched by the mode")
+    scale = np.float32(1.0) / np.float32(N)
+    assert_bitexact(g[:4], np.full((4, 1), -scale, np.float32), "at the tie the .cu comparison lets the hinge term through")
+    assert (da_ref[:4] == 0).all()
+
+
+def test_triplet_step_many_launches_and_graph_replay(hiplib):
+    """The loss of the fused step is reduced inside the launch by its last workgroup through an arrival ticket
+    that the launch hands back zeroed: thousands of launches (more than there are ticket slots) and replays of
+    one captured graph must all return the first launch's bits."""
+    from mms_answer_selection_amd import capi
+    N, D = 4096, 300
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q = torch.randn(N, 1, D, device="cuda", generator=g) * 0.4
+    ap = q + 0.1 * torch.randn(N, 1, D, device="cuda", generator=g)
+    an = torch.randn(N, 1, D, device="cuda", generator=g) * 0.4
+    y = (torch.rand(N, 1, device="cuda", generator=g) < 0.8).float()
+    mk = lambda: dict(s_pos=nan_like((N, 1)), s_neg=nan_like((N, 1)), loss=nan_like((1,)),
+                      dq=nan_like(q.shape), da_pos=nan_like(q.shape), da_neg=nan_like(q.shape))
+    ws = capi.Workspace()
+    two = mk()
+    capi.triplet_euclid_step(q, ap, an, y, margin=0.05, ws=ws, **two)      # default: loss summed by a second launch
+    first = mk()
+    capi.set_triplet_finish_mode("inlaunch")
+    try:
+        _many_launches(capi, q, ap, an, y, ws, mk, first, two)
+    finally:
+        capi.set_triplet_finish_mode("launch")
+
+
+def _many_launches(capi, q, ap, an, y, ws, mk, first, two):
+    if True:
+        capi.triplet_euclid_step(q, ap, an, y, margin=0.05, ws=ws, **first)
+        torch.cuda.synchronize()
+        ref = host(first["loss"]).copy()
+        assert np.isfinite(ref).all()
+        assert_close(ref[0], host(two["loss"])[0], TOL, "in-launch loss vs two-launch loss")
+        assert_bitexact(host(first["dq"]), host(two["dq"]))
+        out = mk()
+        for i in range(1500):
+            capi.triplet_euclid_step(q, ap, an, y, margin=0.05, ws=ws, **out)
+            if i % 250 == 0:
+                assert_bitexact(host(out["loss"]), ref, "launch %d" % i)
+        assert_bitexact(host(out["loss"]), ref)
+        assert_bitexact(host(out["dq"]), host(first["dq"]))
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            gph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gph, stream=cap):
+                for _ in range(4):
+                    capi.triplet_euclid_step(q, ap, an, y, margin=0.05, ws=ws, **out)
+        torch.cuda.current_stream().wait_stream(cap)
+        for _ in range(50):
+            out["loss"].fill_(float("nan"))
+            gph.replay()
+        torch.cuda.synchronize()
+        assert_bitexact(host(out["loss"]), ref, "graph replay")
+
+
 # --------------------------------------------------------------------------- #
 # Fused (q, a+, a-) step == layer-by-layer oracle
 # --------------------------------------------------------------------------- #

@@ -130,18 +130,36 @@ def test_simmatrix_layer_quirks(L, oracle):
     assert top.shape == (N, 1)
     top_ref, scratch_ref = oracle.simmatrix_forward(q, a, W)
     assert_close(top.data, top_ref, TOL)
-    # flagged difference: the reference's forward scribbles Q*W on bottom[1].diff (:58); this layer
-    # keeps the product in a member blob for Backward and leaves the bottom's diff alone
-    assert (ba.diff == 7.0).all()
+    # the reference's forward leaves Q*W in bottom[1].diff (:58): an observable side effect, kept by default
+    assert_close(ba.diff, scratch_ref, TOL)
     dT = r.standard_normal((N, 1)).astype(np.float32)
     top.diff[...] = dT
-    ba.diff[...] = np.nan                            # whatever happens to that diff before Backward
     lay.blobs[0].diff[...] = 1.5                      # accumulates (:73-80)
     lay.Backward([top], [True, True], [bq, ba])
     dq_ref, da_ref, dW_ref = oracle.simmatrix_backward(q, a, W, dT, dW_in=np.full_like(W, 1.5))
     assert_close(bq.diff, dq_ref, TOL)
     assert_close(ba.diff, da_ref, TOL)
     assert_close(lay.blobs[0].diff, dW_ref, TOL)
+    # a second Backward without a Forward in between finds da, not Q*W, in that diff: it recomputes
+    lay.blobs[0].diff[...] = 1.5
+    lay.Backward([top], [True, True], [bq, ba])
+    assert_close(ba.diff, da_ref, TOL)
+    assert_close(lay.blobs[0].diff, dW_ref, TOL)
+    # opt-out: a private copy of the product; then the bottom's diff is left alone by Forward and may be
+    # scribbled on before Backward
+    lay.set_option("private_qw", 1)
+    ba.diff[...] = 7.0
+    lay.Forward([bq, ba], [top])
+    assert (ba.diff == 7.0).all()
+    top.diff[...] = dT
+    ba.diff[...] = np.nan
+    lay.blobs[0].diff[...] = 1.5
+    lay.Backward([top], [True, True], [bq, ba])
+    assert_close(bq.diff, dq_ref, TOL)
+    assert_close(ba.diff, da_ref, TOL)
+    assert_close(lay.blobs[0].diff, dW_ref, TOL)
+    with pytest.raises(KeyError):
+        lay.set_option("no_such_option", 1)
     # pre-loaded blobs are honoured by SimMatrix (:18-20): a second SetUp keeps W
     lay.SetUp([bq, ba], [top])
     assert_bitexact(lay.blobs[0].data, W)
@@ -231,3 +249,34 @@ def test_fatal_errors_abort_like_caffe():
     r = _run_snippet(pre + "L.set_mode_cpu()\nl = L.SimCross()\nq = blob(np.zeros((2,1,8), np.float32))\n"
                      "t = L.Blob()\nl.SetUp([q, q], [t]); l.Forward([q, q], [t])\nprint('survived')")
     assert r.returncode != 0 and "CPU mode" in r.stderr and "survived" not in r.stdout
+
+
+def test_simcross_layer_pins_its_own_euclid_backward_mode(L, oracle):
+    """The arithmetic of the Euclidean backward term is a per-thread setting of the C ABI; a layer can pin its
+    own (mms_layer_set_option) and the thread's setting is untouched afterwards."""
+    from mms_answer_selection_amd import capi
+    N, D = 64, 300
+    r = rng(31)
+    q = (r.standard_normal((N, 1, D)) * 0.4).astype(np.float32)
+    a = (r.standard_normal((N, 1, D)) * 0.4).astype(np.float32)
+    dT = r.standard_normal((N, 1, 1, 1)).astype(np.float32)
+    lay = L.SimCross(dist_mode=1)
+    bq, ba, top = blob(L, q), blob(L, a), L.Blob()
+    lay.SetUp([bq, ba], [top])
+    lay.Forward([bq, ba], [top])
+    top_ref, _, _ = oracle.simcross_forward(1, q, a)
+    dq_ref, da_ref, _, _ = oracle.simcross_backward(1, q, a, top_ref, dT)
+    capi.set_euclid_backward_mode("fp32")
+    try:
+        lay.set_option("euclid_backward_mode", 1)           # reference rounding for this layer only
+        top.diff[...] = dT
+        lay.Backward([top], [True, True], [bq, ba])
+        assert_bitexact(bq.diff, dq_ref)
+        assert_bitexact(ba.diff, da_ref)
+        assert capi.get_euclid_backward_mode() == "fp32"    # the thread's mode was put back
+        lay.set_option("euclid_backward_mode", -1)          # back to the thread's mode: <= 2 ulp, not bit-exact
+        lay.Backward([top], [True, True], [bq, ba])
+        ulps = np.abs(bq.diff.view(np.int32).astype(np.int64) - dq_ref.view(np.int32).astype(np.int64))
+        assert ulps.max() <= 2
+    finally:
+        capi.set_euclid_backward_mode("reference")          # what conftest.py runs the GPU tests in
