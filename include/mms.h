@@ -143,6 +143,16 @@ int mms_simcross_forward_backward_f32(int dist_mode, int N, int W1, int W2,
  * the exactly-widened inputs -- top equals the fp32 result on those inputs bit
  * for bit and dq/da are its correctly rounded (RNE) halves.  D % 8 == 0,
  * D <= 2048.  The reference has no fp16 instantiation (common.hpp:41-44). */
+/* How the fp16-storage entry points sum the D squares of a pair (per calling thread):
+ *   MMS_F16_DISTANCE_ORDERED (default): d-ascending fp32 sum, the order of sim_cross_layer.cpp:100-105 -- scores
+ *       bit-identical to the fp32 layer run on the fp16-rounded inputs (and so is any ranking);
+ *   MMS_F16_DISTANCE_TREE: a fixed tree sum (deterministic, ~1e-6 relative from the ordered sum; SURVEY 8(d) holds
+ *       this configuration to 1e-3 against the fp32 oracle because the reference has no fp16 instantiation to
+ *       reproduce).  2.3x faster at D = 1024: the ordered chain is 55 % of the ordered kernel. */
+#define MMS_F16_DISTANCE_ORDERED 0
+#define MMS_F16_DISTANCE_TREE 1
+int mms_set_f16_distance_mode(int mode);
+int mms_get_f16_distance_mode(void);
 int mms_simcross_euclid_forward_f16(int N, int D, const void* q_f16, const void* a_f16,
                                     float* top, void* stream);
 int mms_simcross_euclid_forward_backward_f16(int N, int D, const void* q_f16,

@@ -51,6 +51,8 @@ _SIGNATURES = {
     "mms_get_euclid_backward_mode": (_i, []),
     "mms_dot_f32": (_i, [_i, _vp, _vp, _vp, _vp]),
     "mms_dot_f64": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "mms_set_f16_distance_mode": (_i, [_i]),
+    "mms_get_f16_distance_mode": (_i, []),
     "mms_set_triplet_finish_mode": (_i, [_i]),
     "mms_get_triplet_finish_mode": (_i, []),
     "mms_set_pairrank_hinge_mode": (_i, [_i]),
@@ -326,6 +328,13 @@ def set_pairrank_hinge_mode(mode):
     reference's .cu kernel.  Per calling thread."""
     m = {"cpu": 0, "gpu": 1}[mode] if isinstance(mode, str) else int(mode)
     check(lib().mms_set_pairrank_hinge_mode(m), "mms_set_pairrank_hinge_mode")
+
+
+def set_f16_distance_mode(mode):
+    """'ordered' (default): the reference's d-ascending fp32 sum, bit-identical scores; 'tree': fixed tree sum,
+    ~1e-6 relative, no ordered chain.  Per calling thread; fp16-storage entry points only."""
+    m = {"ordered": 0, "tree": 1}[mode] if isinstance(mode, str) else int(mode)
+    check(lib().mms_set_f16_distance_mode(m), "mms_set_f16_distance_mode")
 
 
 def set_triplet_finish_mode(mode):

@@ -274,6 +274,139 @@ __device__ __forceinline__ float chain_sum_speculative(const float4* img4, int D
   return s3;
 }
 
+// ---- quad-shared variant for WIDE rows (one pair per wave; cfg 5: D = 1024) --------------------------------
+// With a whole wave on one pair, every lane of chain_sum_speculative reads its entire segment from LDS
+// (identical addresses within a segment: 86 ds_read_b128 per lane per pair) and the LDS -> VGPR return path
+// -- 8 LDS cycles per wave-wide 16-byte read, whatever is broadcast -- paces the kernel: 2,752 LDS cycles per
+// four pairs per CU against 1,376 cycles of packed adds (tools/f16abl.sh).  Here the four lanes
+// of a QUAD share one copy of the addends: lane ql of a quad reads only the float4s u = ql (mod 4) of its
+// segment (a quarter of the LDS traffic) and every add takes its addend from the owning lane through the
+// DPP quad_perm broadcast of the add instruction itself (v_add_f32_dpp: no extra instruction, no LDS).
+// Packed adds have no DPP form, so a lane's two running sums cost two adds per step instead of one packed
+// add: 30 % more VALU issue, a quarter of the LDS return traffic.
+//   quad 0           walks segment 0 from 0 (four identical copies)
+//   quads 1 .. 6     24 lanes, 48 start values pred1 + k ulps, -24 <= k <= 23
+//   quads 7 .. 15    36 lanes, 72 start values pred2 + k ulps, -36 <= k <= 35
+// Segments are quad_h4(D4) float4 long (a multiple of 4, so that every lane of a quad runs the same number
+// of reads); the image is padded with zeros to three segments as before.  Same stitching rule, same exact
+// re-walk on a miss: the result is the reference's sum bit for bit.
+__device__ __host__ __forceinline__ int quad_h4(int D4) { return 4 * ((D4 + 11) / 12); }
+struct QuadPlan { static constexpr int H1 = 24, Q1 = 1, N1 = 6, H2 = 36; };   // quads of segment 1: [Q1, Q1+N1)
+
+// s += (value of `a` in quad lane O), one instruction.  Inline asm: left to the compiler, the two running sums
+// of a lane are packed into v_pk_add_f32 (which has no DPP form) behind a v_mov_b32_dpp per step.  The DPP
+// source operand is never written by a VALU instruction (the addends come straight from ds_read), so the
+// VALU-write -> DPP-read hazard cannot arise between these statements.
+#define MMS_QUAD_STEP4(P)                                                                      \
+  asm("v_add_f32_dpp %0, %2, %0 quad_perm:[" P "] row_mask:0xf bank_mask:0xf\n\t"             \
+      "v_add_f32_dpp %1, %2, %1 quad_perm:[" P "] row_mask:0xf bank_mask:0xf\n\t"             \
+      "v_add_f32_dpp %0, %3, %0 quad_perm:[" P "] row_mask:0xf bank_mask:0xf\n\t"             \
+      "v_add_f32_dpp %1, %3, %1 quad_perm:[" P "] row_mask:0xf bank_mask:0xf\n\t"             \
+      "v_add_f32_dpp %0, %4, %0 quad_perm:[" P "] row_mask:0xf bank_mask:0xf\n\t"             \
+      "v_add_f32_dpp %1, %4, %1 quad_perm:[" P "] row_mask:0xf bank_mask:0xf\n\t"             \
+      "v_add_f32_dpp %0, %5, %0 quad_perm:[" P "] row_mask:0xf bank_mask:0xf\n\t"             \
+      "v_add_f32_dpp %1, %5, %1 quad_perm:[" P "] row_mask:0xf bank_mask:0xf"                  \
+      : "+v"(sx), "+v"(sy) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w))
+// Both running sums of a lane advance by the four values of float4 `v` held by quad lane O: eight
+// v_add_f32_dpp in ONE asm statement (left to the compiler, the two sums are packed into v_pk_add_f32 --
+// which has no DPP form -- behind a v_mov_b32_dpp per step; one statement per add drew a padding s_nop each).
+// The DPP source operands are never VALU results (the addends come straight from ds_read) and the
+// accumulators are ordinary src1 operands, so no VALU-write -> DPP-read hazard exists inside the string.
+template <int O>
+__device__ __forceinline__ void quad_step4(float& sx, float& sy, const float4& v) {
+  static_assert(O >= 0 && O < 4, "quad lane");
+  if (O == 0) MMS_QUAD_STEP4("0,0,0,0");
+  if (O == 1) MMS_QUAD_STEP4("1,1,1,1");
+  if (O == 2) MMS_QUAD_STEP4("2,2,2,2");
+  if (O == 3) MMS_QUAD_STEP4("3,3,3,3");
+}
+#undef MMS_QUAD_STEP4
+// r4: this lane's segment in LDS; the lane reads float4s ql, ql + 4, ...; h4 % 4 == 0
+__device__ __forceinline__ float2v chain_sum_lds_quad(const float4* r4, int h4, int ql, float2v init) {
+  float sx = init.x, sy = init.y;
+  const float4* mine = r4 + ql;
+  const int nm = h4 >> 2;                          // reads per lane
+  float4 va[8], vb[8];
+  auto steps = [&](const float4 (&v)[8], int cnt) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u < cnt) {
+        quad_step4<0>(sx, sy, v[u]);
+        quad_step4<1>(sx, sy, v[u]);
+        quad_step4<2>(sx, sy, v[u]);
+        quad_step4<3>(sx, sy, v[u]);
+      }
+    }
+  };
+  const int nb = nm >> 3;
+  if (nb > 0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) va[u] = mine[4 * u];
+  }
+  int b = 0;
+  for (; b + 2 <= nb; b += 2) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) vb[u] = mine[4 * ((b + 1) * 8 + u)];
+    steps(va, 8);
+    if (b + 2 < nb) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) va[u] = mine[4 * ((b + 2) * 8 + u)];
+    }
+    steps(vb, 8);
+  }
+  if (b < nb) steps(va, 8);
+  // remainder (nm % 8 reads): EVERY lane of the quad executes the same steps (the broadcasts need all four)
+  const int rem = nm - nb * 8;
+  if (rem > 0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) va[u] = mine[4 * (nb * 8 + (u < rem ? u : 0))];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u < rem) {                               // wave-uniform
+        quad_step4<0>(sx, sy, va[u]);
+        quad_step4<1>(sx, sy, va[u]);
+        quad_step4<2>(sx, sy, va[u]);
+        quad_step4<3>(sx, sy, va[u]);
+      }
+    }
+  }
+  return (float2v){sx, sy};
+}
+
+// `img4` the pair's image (3 * h4 float4, zero padded), `pred1` / `pred2` tree sums of segment 0 and segments
+// 0-1, `lane` 0..63 (one pair per wave).  Returns the full sum in every lane.
+__device__ __forceinline__ float chain_sum_speculative_quad(const float4* img4, int h4, float pred1, float pred2,
+                                                            int lane) {
+  typedef QuadPlan P;
+  const int qd = lane >> 2, ql = lane & 3;
+  const int seg = (qd < P::Q1) ? 0 : (qd < P::Q1 + P::N1 ? 1 : 2);
+  const int first1 = 4 * P::Q1, first2 = 4 * (P::Q1 + P::N1);          // first lane of segments 1 and 2
+  const int c0 = (seg == 1) ? 2 * (lane - first1) - P::H1 : 2 * (lane - first2) - P::H2;   // ulp offset of slot 0
+  const int pbits = __float_as_int(seg == 1 ? pred1 : pred2);
+  float2v start;
+  start.x = (seg == 0) ? 0.0f : __int_as_float(pbits + c0);
+  start.y = (seg == 0) ? 0.0f : __int_as_float(pbits + c0 + 1);
+  __builtin_amdgcn_s_setprio(3);
+  const float2v end = chain_sum_lds_quad(img4 + seg * h4, h4, ql, start);
+  // segment 0 -> 1
+  const float s1 = __shfl(end.x, 0, 64);
+  const int k1 = __float_as_int(s1) - __float_as_int(pred1) + P::H1;     // slot index in segment 1
+  const bool hit1 = (k1 >= 0) && (k1 < 8 * P::N1);
+  const int l1 = first1 + ((hit1 ? k1 : 0) >> 1);
+  const float e1x = __shfl(end.x, l1, 64), e1y = __shfl(end.y, l1, 64);
+  float s2 = (k1 & 1) ? e1y : e1x;
+  if (!hit1) { MMS_COUNT_MISS(); s2 = chain_sum_lds(img4 + h4, h4, s1); }   // re-walk, exact
+  // segment 1 -> 2
+  const int k2 = __float_as_int(s2) - __float_as_int(pred2) + P::H2;
+  const bool hit2 = (k2 >= 0) && (k2 < 2 * (64 - first2));
+  const int l2 = first2 + ((hit2 ? k2 : 0) >> 1);
+  const float e2x = __shfl(end.x, l2, 64), e2y = __shfl(end.y, l2, 64);
+  float s3 = (k2 & 1) ? e2y : e2x;
+  if (!hit2) { MMS_COUNT_MISS(); s3 = chain_sum_lds(img4 + 2 * h4, h4, s2); }
+  __builtin_amdgcn_s_setprio(0);
+  return s3;
+}
+
 // Compile-time-length variants for the widths the wave-pair kernel is specialised
 // for (simcross_elementwise.hip: euclid_pair32_kernel).  H4 (float4s per segment)
 // is a constant, so

@@ -67,6 +67,8 @@ int pairrank_hinge_mode();
 void set_pairrank_hinge_mode(int m);
 int triplet_finish_mode();
 void set_triplet_finish_mode(int m);
+int f16_distance_mode();
+void set_f16_distance_mode(int m);
 // f64_paths.hip
 size_t simcross_workspace_bytes_f64(int mode, int N, int W1, int W2, int D, int M);
 int simcross_forward_f64(int mode, int N, int W1, int W2, int D, int M, const double* q, const double* a,
@@ -412,6 +414,12 @@ int mms_set_triplet_finish_mode(int mode) {
   return MMS_OK;
 }
 int mms_get_triplet_finish_mode(void) { return triplet_finish_mode(); }
+int mms_set_f16_distance_mode(int mode) {
+  if (mode != MMS_F16_DISTANCE_ORDERED && mode != MMS_F16_DISTANCE_TREE) return MMS_ERR_INVALID_ARG;
+  set_f16_distance_mode(mode);
+  return MMS_OK;
+}
+int mms_get_f16_distance_mode(void) { return f16_distance_mode(); }
 
 // ---- double instantiation (csrc/f64_paths.hip): same contracts as the _f32 entry points ----
 size_t mms_simcross_workspace_bytes_f64(int dist_mode, int N, int W1, int W2, int D, int M) {

@@ -367,6 +367,11 @@ __global__ __launch_bounds__(64 * WPB) void euclid_pair32_kernel(
   MMS_STAMP(7);
 }
 
+// How the fp16-storage kernels sum a pair's squares (include/mms.h: mms_set_f16_distance_mode); per calling thread.
+static thread_local int t_f16_distance_mode = MMS_F16_DISTANCE_ORDERED;
+int f16_distance_mode() { return t_f16_distance_mode; }
+void set_f16_distance_mode(int m) { t_f16_distance_mode = m; }
+
 // ---- fp16 storage, fp32 arithmetic (BASELINE cfg 5) --------------------------
 // Same wave-centric structure with one pair per wave (cfg 5 is D = 1024): q, a,
 // dq, da live in HBM as IEEE half (half the bytes per pair: s = 2 in SURVEY
@@ -384,7 +389,13 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // VALU issue cost per pair, but the narrower speculation windows (+-12 / +-15 ulp instead of +-25 / +-36)
 // miss too often there (see simcross_euclid_rows_f16); a miss re-walks one segment exactly, so results
 // never change, only time.
-template <int NIT, int RW, bool BWD>
+// QUAD (RW == 1 only): the quad-shared chain of euclid_math.h (a quarter of the LDS operand traffic).
+// TREE (RW == 1 only): the distance is the TREE sum of the squares that the ordered variants use only to centre
+// their speculation windows -- no ordered chain, 8.3 instead of 19 us at cfg 5's shard.  The reference has no
+// fp16 instantiation, so there is no reference rounding to reproduce; SURVEY 8(d) holds cfg 5 to 1e-3 relative
+// against the fp32 oracle on the fp16-rounded inputs, and this sum is within ~1e-6 of it.  Opt-in
+// (mms_set_f16_distance_mode): the default stays the ordered sum, bit-identical to the fp32 layer's.
+template <int NIT, int RW, bool BWD, bool QUAD = false, bool TREE = false>
 __global__ __launch_bounds__(256) void euclid_rows_wave_f16_kernel(
     const _Float16* __restrict__ q, const _Float16* __restrict__ a,
     const float* __restrict__ top_diff, float* __restrict__ top_out,
@@ -400,7 +411,7 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_f16_kernel(
   const size_t base8 = (size_t)row0 * D8;
   const half8* q8 = reinterpret_cast<const half8*>(q) + base8;
   const half8* a8 = reinterpret_cast<const half8*>(a) + base8;
-  const int st4 = spec_stride4(D4), h4 = spec_h4(D4);
+  const int h4 = QUAD ? quad_h4(D4) : spec_h4(D4), st4 = 3 * h4;
   float4* sq4 = lds4 + (size_t)wave * RW * st4;
 
   half8 x[NIT], y[NIT];
@@ -417,6 +428,7 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_f16_kernel(
   if (BWD) g = top_diff[row0 + grow];
 
   float4 df[2 * NIT];
+  float tree_total = 0.f;
   float2v pred[RW];                              // per pair: (pred1, pred2) partial sums
 #pragma unroll
   for (int r = 0; r < RW; ++r) pred[r] = (float2v){0.f, 0.f};
@@ -436,8 +448,9 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_f16_kernel(
       float4 s;
       s.x = d.x * d.x; s.y = d.y * d.y; s.z = d.z * d.z; s.w = d.w * d.w;
       const int i4 = 2 * ir + hh;                // float4 index inside the pair's image
-      if (i < n8) sq4[(r1 ? st4 : 0) + i4] = s;
+      if (!TREE && i < n8) sq4[(r1 ? st4 : 0) + i4] = s;
       const float s4 = (i < n8) ? (s.x + s.y) + (s.z + s.w) : 0.f;
+      if (TREE) tree_total += s4;
       float2v c;
       c.x = (i4 < h4) ? s4 : 0.f;
       c.y = (i4 < 2 * h4) ? s4 : 0.f;
@@ -458,7 +471,9 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_f16_kernel(
 #if defined(MMS_F16ABL) && MMS_F16ABL == 1     // dev-only timing ablation (tools/f16bench.hip): no chain
   const float dist = my2;
 #else
-  const float dist = chain_sum_speculative<LPR>(sq4 + grow * st4, D4, my1, my2, j, grp * LPR);
+  const float dist = TREE ? wave_sum(tree_total)
+                   : QUAD ? chain_sum_speculative_quad(sq4, h4, my1, my2, lane)
+                          : chain_sum_speculative<LPR>(sq4 + grow * st4, D4, my1, my2, j, grp * LPR);
 #endif
   const float T = 1.0f / (1.0f + sqrtf(dist));
   if (j == 0 && grp < rows) top_out[row0 + grp] = T;
@@ -516,7 +531,11 @@ int simcross_euclid_rows_f16(int N, int D, const void* q, const void* a, const f
   const int rw = D <= 400 ? 2 : 1;
   const int nit = (rw * D8 + 63) / 64;
   const unsigned grid = (unsigned)((N + 4 * rw - 1) / (4 * rw));
-  const size_t lds = (size_t)4 * rw * 3 * ((2 * D8 + 2) / 3) * sizeof(float4);
+  // one pair per wave: the quad-shared chain (MMS_F16_CHAIN=lanes selects the per-lane chain, for A/B timing)
+  static const bool quad_off = [] { const char* e = std::getenv("MMS_F16_CHAIN"); return e && !std::strcmp(e, "lanes"); }();
+  const bool quad = rw == 1 && !quad_off;
+  const bool tree = f16_distance_mode() == MMS_F16_DISTANCE_TREE;
+  const size_t lds = (size_t)4 * rw * 3 * (quad ? quad_h4(2 * D8) : (2 * D8 + 2) / 3) * sizeof(float4);
   const _Float16* qh = static_cast<const _Float16*>(q);
   const _Float16* ah = static_cast<const _Float16*>(a);
   _Float16* dqh = static_cast<_Float16*>(dq);
@@ -530,20 +549,57 @@ int simcross_euclid_rows_f16(int N, int D, const void* q, const void* a, const f
       hipLaunchKernelGGL((euclid_rows_wave_f16_kernel<n, r, false>), dim3(grid), dim3(256), lds, s,   \
                          qh, ah, top_diff, top, dqh, dah, N, D8);                                     \
   } while (0)
-  if (rw == 2) {
+  if (tree) {
+    // one pair per wave whatever D: no speculation windows to fit
+    const int nit1 = (D8 + 63) / 64;
+    const unsigned grid1 = (unsigned)((N + 3) / 4);
+#define MMS_F16_TREE(n)                                                                               \
+  do {                                                                                                \
+    if (bwd)                                                                                          \
+      hipLaunchKernelGGL((euclid_rows_wave_f16_kernel<n, 1, true, false, true>), dim3(grid1),         \
+                         dim3(256), 16, s, qh, ah, top_diff, top, dqh, dah, N, D8);                   \
+    else                                                                                              \
+      hipLaunchKernelGGL((euclid_rows_wave_f16_kernel<n, 1, false, false, true>), dim3(grid1),        \
+                         dim3(256), 16, s, qh, ah, top_diff, top, dqh, dah, N, D8);                   \
+  } while (0)
+    switch (nit1) {
+      case 1: MMS_F16_TREE(1); break;
+      case 2: MMS_F16_TREE(2); break;
+      case 3: MMS_F16_TREE(3); break;
+      default: MMS_F16_TREE(4); break;
+    }
+#undef MMS_F16_TREE
+  } else if (rw == 2) {
     switch (nit) {
       case 1: MMS_F16_LAUNCH(1, 2); break;
       case 2: MMS_F16_LAUNCH(2, 2); break;
       case 3: MMS_F16_LAUNCH(3, 2); break;
       default: MMS_F16_LAUNCH(4, 2); break;
     }
-  } else {
+  } else if (!quad) {
     switch (nit) {
       case 1: MMS_F16_LAUNCH(1, 1); break;
       case 2: MMS_F16_LAUNCH(2, 1); break;
       case 3: MMS_F16_LAUNCH(3, 1); break;
       default: MMS_F16_LAUNCH(4, 1); break;
     }
+  } else {
+#define MMS_F16_QUAD(n)                                                                               \
+  do {                                                                                                \
+    if (bwd)                                                                                          \
+      hipLaunchKernelGGL((euclid_rows_wave_f16_kernel<n, 1, true, true>), dim3(grid), dim3(256), lds, \
+                         s, qh, ah, top_diff, top, dqh, dah, N, D8);                                  \
+    else                                                                                              \
+      hipLaunchKernelGGL((euclid_rows_wave_f16_kernel<n, 1, false, true>), dim3(grid), dim3(256),     \
+                         lds, s, qh, ah, top_diff, top, dqh, dah, N, D8);                             \
+  } while (0)
+    switch (nit) {
+      case 1: MMS_F16_QUAD(1); break;
+      case 2: MMS_F16_QUAD(2); break;
+      case 3: MMS_F16_QUAD(3); break;
+      default: MMS_F16_QUAD(4); break;
+    }
+#undef MMS_F16_QUAD
   }
 #undef MMS_F16_LAUNCH
   return launch_status();

@@ -236,6 +236,45 @@ def test_euclid_fp16_storage(cfg, oracle, hiplib):
     assert (host(ga).view(np.uint16) == da_ref.astype(np.float16).view(np.uint16)).all(), "da halves"
 
 
+@pytest.mark.parametrize("cfg", [(8192, 1024), (33, 1024), (17, 2048), (9, 304), (64, 512)])
+def test_euclid_fp16_storage_tree_mode(cfg, oracle, hiplib):
+    """The opt-in tree sum of the fp16-storage path (no ordered chain): SURVEY 8(d) holds cfg 5 to 1e-3 relative
+    against the fp32 oracle on the fp16-rounded inputs; the tree sum is within 1e-5 of it, deterministic, and the
+    default (ordered) mode is back to bit-exactness afterwards."""
+    from mms_answer_selection_amd import capi
+    N, D = cfg
+    r = rng(N + 3 * D)
+    qf, af = qa(r, N, 1, 1, D)
+    qh, ah = qf.astype(np.float16), af.astype(np.float16)
+    dT = r.standard_normal((N, 1, 1, 1)).astype(np.float32)
+    q32, a32 = qh.astype(np.float32), ah.astype(np.float32)
+    top_ref, _, _ = oracle.simcross_forward(1, q32, a32)
+    dq_ref, da_ref, _, _ = oracle.simcross_backward(1, q32, a32, top_ref, dT)
+    qd, ad = torch.from_numpy(qh).cuda(), torch.from_numpy(ah).cuda()
+    mk16 = lambda: torch.full(qh.shape, float("nan"), dtype=torch.float16, device="cuda")
+    capi.set_f16_distance_mode("tree")
+    try:
+        top, gq, ga = nan_like(top_ref.shape), mk16(), mk16()
+        capi.simcross_euclid_forward_backward_f16(qd, ad, dev(dT), top, gq, ga)
+        top_b, gq_b, ga_b = nan_like(top_ref.shape), mk16(), mk16()
+        capi.simcross_euclid_forward_backward_f16(qd, ad, dev(dT), top_b, gq_b, ga_b)
+        fwd = nan_like(top_ref.shape)
+        capi.simcross_euclid_forward_f16(qd, ad, fwd)
+    finally:
+        capi.set_f16_distance_mode("ordered")
+    assert_close(host(top), top_ref, 1e-5, "top (tree sum)")           # bar for this configuration: 1e-3
+    assert_bitexact(host(top_b), host(top), "deterministic")
+    assert_bitexact(host(fwd), host(top), "forward-only == fused")
+    assert (host(gq_b).view(np.uint16) == host(gq).view(np.uint16)).all()
+    g, ref = host(gq).astype(np.float32), dq_ref
+    assert np.abs(g - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max()), "dq within the fp16 grid of the oracle's"
+    g, ref = host(ga).astype(np.float32), da_ref
+    assert np.abs(g - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+    top2 = nan_like(top_ref.shape)
+    capi.simcross_euclid_forward_f16(qd, ad, top2)
+    assert_bitexact(host(top2), top_ref, "ordered mode is the default again")
+
+
 def test_euclid_unaligned_views_take_scalar_path(oracle, hiplib):
     """Pointers that are not 16-byte aligned must still give the same bits."""
     from mms_answer_selection_amd import capi
