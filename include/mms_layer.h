@@ -61,6 +61,36 @@ void mms_layer_set_param_propagate_down(mms_layer_t* l, int i, int v);
  *             bottom[1]'s diff like the reference (sim_matrix_layer.cpp:58) and Backward scales it there. */
 int mms_layer_set_option(mms_layer_t* l, const char* key, int value);
 
+/* ---- Whole nets: the generated net files of the driver, unmodified -------------------------------------------
+ * `prototxt` is a NetParameter in protobuf text format (src/caffe/proto/caffe.proto:63-110, as
+ * python/caffe/net_spec.py:31-79 writes it; examples/trec_qa_w2v_mms/do_trec_qa_clean.py:608-615 generates three
+ * per run).  Layers are filtered by `phase` (0 TRAIN, 1 TEST; include / exclude rules, net.cpp:272-330), blobs are
+ * wired by name (a top named like its bottom is computed in place), parameters named alike are shared
+ * (net.cpp:450-530).  Every layer type this library implements is instantiated; the others (Convolution, Pooling,
+ * Dropout, InnerProduct, Softmax, ...) are LISTED and SKIPPED -- their parameter messages are parsed over, and a
+ * blob that only they produce is an input of the part that runs: fill it through mms_net_blob() before
+ * mms_net_setup().  mms_net_setup() = Layer::SetUp for every supported layer whose bottoms have a shape, in file
+ * order (returns how many can run; mms_net_layer_why_not() says what a supported but idle layer is waiting for);
+ * mms_net_forward() / mms_net_backward() = Net::ForwardFromTo / BackwardFromTo over those layers (net.cpp:535-591)
+ * -- all forwards, then all backwards.  Handles returned by mms_net_blob / mms_net_layer are borrowed. */
+typedef struct mms_net mms_net_t;
+mms_net_t* mms_net_create(const char* prototxt, int phase, char* err, int err_len);
+void mms_net_destroy(mms_net_t* n);
+const char* mms_net_name(const mms_net_t* n);
+int mms_net_num_layers(const mms_net_t* n);
+const char* mms_net_layer_name(const mms_net_t* n, int i);
+const char* mms_net_layer_type(const mms_net_t* n, int i);
+int mms_net_layer_supported(const mms_net_t* n, int i);
+int mms_net_layer_runnable(const mms_net_t* n, int i);
+const char* mms_net_layer_why_not(const mms_net_t* n, int i);
+mms_layer_t* mms_net_layer(mms_net_t* n, int i);
+int mms_net_num_blobs(const mms_net_t* n);
+const char* mms_net_blob_name(const mms_net_t* n, int i);
+mms_blob_t* mms_net_blob(mms_net_t* n, const char* name);
+int mms_net_setup(mms_net_t* n);
+float mms_net_forward(mms_net_t* n);
+void mms_net_backward(mms_net_t* n);
+
 /* Caffe::set_mode (include/caffe/common.hpp): 0 = CPU, 1 = GPU (default).
  * This library is GPU-only: Forward/Backward in CPU mode is a fatal error. */
 void mms_caffe_set_mode(int gpu);

@@ -320,7 +320,26 @@ struct LayerParameter {  // caffe.proto:310-416 (subset)
   const SimCrossParameter& sim_cross_param() const { return sim_cross_param_; }
   const SimMatrixParameter& sim_matrix_param() const { return sim_matrix_param_; }
   const PairRankLossParameter& pair_rank_loss_param() const { return pair_rank_loss_param_; }
+  // caffe.proto:326-341: phase / include / exclude (NetStateRule: only its `phase` is interpreted here)
+  int phase_ = -1;                       // -1 unset, 0 TRAIN, 1 TEST
+  vector<int> include_phase_, exclude_phase_;
+  vector<string> skipped_fields_;        // *_param messages of layer types this library does not implement
 };
+
+// caffe.proto:63-110 (subset): what the driver's generated net files hold
+struct NetParameter {
+  string name_;
+  vector<LayerParameter> layer_;
+  vector<string> input_;
+  vector<vector<int> > input_shape_;
+  bool force_backward_ = false;
+};
+// Reads a whole net in protobuf text format (`name: ... layer { ... } layer { ... } ...`; the V1 spelling
+// `layers { ... }` is accepted for the fields it shares).  Parameter messages of layer types outside this
+// library (convolution_param, pooling_param, ...) are skipped and recorded, not rejected: the net file
+// python/caffe/net_spec.py writes for network_v4 (examples/trec_qa_w2v_mms/do_trec_qa_clean.py:608-615)
+// must load unmodified.
+bool ReadNetParameterFromText(const string& text, NetParameter* out, string* err);
 
 // Reads ONE `layer { ... }` message (or its body) in protobuf text format.
 // Unknown fields are a fatal error, as with protobuf's TextFormat.

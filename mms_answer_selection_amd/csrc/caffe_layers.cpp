@@ -8,6 +8,8 @@
 // bodies are not restated here at all -- they are calls into the C ABI.
 // CPU mode is deliberately absent: this library is the GPU implementation,
 // and a silent host fallback would void every parity claim.
+#include <map>
+#include <set>
 #include "caffe_api.hpp"
 
 #include <cctype>
@@ -1013,8 +1015,24 @@ class Parser {
     if (n == "bottom") { if (!scalar(&v)) return false; lp->bottom_.push_back(v.text); return true; }
     if (n == "top") { if (!scalar(&v)) return false; lp->top_.push_back(v.text); return true; }
     if (n == "loss_weight") { float f; if (!scalar(&v) || !as_float(v, &f)) return false; lp->loss_weight_.push_back(f); return true; }
-    if (n == "phase" || n == "propagate_down") { return scalar(&v); }
-    if (n == "include" || n == "exclude") return skip_value();
+    if (n == "propagate_down") { return scalar(&v); }
+    if (n == "phase") { if (!scalar(&v)) return false; lp->phase_ = (v.text == "TEST" || v.text == "1") ? 1 : 0; return true; }
+    if (n == "include" || n == "exclude") {
+      vector<int>* dst = n == "include" ? &lp->include_phase_ : &lp->exclude_phase_;
+      bool saw_phase = false;
+      if (!message([&](const string& m) {
+            if (m == "phase") {
+              Tok w;
+              if (!scalar(&w)) return false;
+              dst->push_back((w.text == "TEST" || w.text == "1") ? 1 : 0);
+              saw_phase = true;
+              return true;
+            }
+            return skip_value();                      // min_level / max_level / stage / not_stage: not interpreted
+          })) return false;
+      if (!saw_phase) dst->push_back(-1);              // a rule without a phase matches every phase
+      return true;
+    }
     if (n == "param") {
       ParamSpec ps;
       if (!message([&](const string& m) {
@@ -1102,13 +1120,71 @@ class Parser {
         return false;
       });
     }
+    // parameter messages of layer types this library does not implement (whole-net files only)
+    if (tolerant_ && n.size() > 6 && n.compare(n.size() - 6, 6, "_param") == 0) {
+      lp->skipped_fields_.push_back(n);
+      return skip_value();
+    }
+    if (tolerant_ && (n == "blobs" || n == "blobs_lr" || n == "weight_decay")) return skip_value();   // V1 leftovers
     return false;
   }
+  bool tolerant_ = false;
  private:
   Lexer lex_;
   string err_;
 };
 }  // namespace
+
+bool ReadNetParameterFromText(const string& text, NetParameter* out, string* err) {
+  Parser p(text);
+  p.tolerant_ = true;
+  *out = NetParameter();
+  bool ok = p.advance();
+  while (ok && p.cur_.kind == Tok::IDENT) {
+    const string name = p.cur_.text;
+    ok = p.advance();
+    if (!ok) break;
+    Tok v;
+    if (name == "layer" || name == "layers") {
+      LayerParameter lp;
+      ok = p.message([&](const string& n) { return p.layer_field(n, &lp); });
+      if (ok && lp.type_.empty()) ok = p.fail("layer '" + lp.name_ + "' has no type");
+      if (ok) out->layer_.push_back(lp);
+    } else if (name == "name") {
+      ok = p.scalar(&v);
+      if (ok) out->name_ = v.text;
+    } else if (name == "input") {
+      ok = p.scalar(&v);
+      if (ok) out->input_.push_back(v.text);
+    } else if (name == "input_shape") {
+      vector<int> shape;
+      ok = p.message([&](const string& m) {
+        Tok w;
+        int d;
+        if (m != "dim" || !p.scalar(&w) || !p.as_int(w, &d)) return false;
+        shape.push_back(d);
+        return true;
+      });
+      if (ok) out->input_shape_.push_back(shape);
+    } else if (name == "input_dim") {
+      int d;
+      ok = p.scalar(&v) && p.as_int(v, &d);
+      if (ok) {
+        if (out->input_shape_.empty() || out->input_shape_.back().size() == 4) out->input_shape_.push_back(vector<int>());
+        out->input_shape_.back().push_back(d);
+      }
+    } else if (name == "force_backward") {
+      ok = p.scalar(&v) && p.as_bool(v, &out->force_backward_);
+    } else if (name == "state" || name == "debug_info") {
+      ok = p.skip_value();
+    } else {
+      ok = p.fail("unknown net field '" + name + "'");
+    }
+  }
+  if (ok && p.cur_.kind != Tok::END) ok = p.fail("trailing input after the net");
+  if (!ok && err) *err = p.err().empty() ? "parse error" : p.err();
+  return ok;
+}
 
 bool ReadLayerParameterFromText(const string& text, LayerParameter* out, string* err) {
   Parser p(text);
@@ -1130,6 +1206,134 @@ bool ReadLayerParameterFromText(const string& text, LayerParameter* out, string*
 
 }  // namespace caffe
 
+
+// ================================ PathNet: the path's layers of a whole net =================================
+// What Net::Init / ForwardFromTo / BackwardFromTo (src/caffe/net.cpp:40-270, 535-591) do for the layers of a
+// generated net file that THIS library implements: phase filtering (net.cpp:272-330 StateMeetsRule, phase
+// only), blobs wired by name with in-place tops sharing their bottom's blob (net.cpp:385-420), parameters
+// shared by `param { name }` (net.cpp:450-530 AppendParam), layers run in file order.  Layers of other types
+// are listed and skipped; a blob only they produce is an input the host fills before SetUp.
+namespace caffe {
+struct PathNetLayer {
+  LayerParameter param;
+  shared_ptr<Layer<float> > layer;        // null: the type is outside this library
+  vector<Blob<float>*> bottom, top;
+  vector<string> bottom_names, top_names;
+  bool runnable = false;
+  string why_not;                          // for a supported layer that cannot run: what is missing
+};
+class PathNet {
+ public:
+  PathNet(const NetParameter& np, int phase) : name_(np.name_), phase_(phase) {
+    for (size_t i = 0; i < np.input_.size(); ++i) {
+      Blob<float>* b = blob(np.input_[i], true);
+      if (i < np.input_shape_.size() && !np.input_shape_[i].empty()) b->Reshape(np.input_shape_[i]);
+    }
+    for (const LayerParameter& lp : np.layer_) {
+      if (!included(lp)) continue;
+      PathNetLayer L;
+      L.param = lp;
+      for (const string& bn : lp.bottom_) { L.bottom.push_back(blob(bn, true)); L.bottom_names.push_back(bn); }
+      for (const string& tn : lp.top_) { L.top.push_back(blob(tn, true)); L.top_names.push_back(tn); }   // same name = same blob (in place)
+      if (LayerRegistry<float>::Registry().count(lp.type())) L.layer = LayerRegistry<float>::CreateLayer(lp);
+      layers_.push_back(L);
+    }
+  }
+  // SetUp of every supported layer whose bottoms have a shape, in file order; returns the number that can run
+  int SetUp() {
+    int n = 0;
+    for (PathNetLayer& L : layers_) {
+      L.runnable = false;
+      L.why_not.clear();
+      if (!L.layer) { L.why_not = "layer type '" + L.param.type() + "' is not implemented by this library"; continue; }
+      for (size_t b = 0; b < L.bottom.size(); ++b)
+        if (L.bottom[b]->count() == 0 && L.why_not.empty()) L.why_not = "bottom '" + L.bottom_names[b] + "' has no shape (fill it before SetUp)";
+      if (!L.why_not.empty()) continue;
+      // AutoTopBlobs (layer.hpp:67-74 / net.cpp:150-166): anonymous tops up to the layer's need
+      if (L.layer->AutoTopBlobs()) {
+        const int need = std::max(L.layer->MinTopBlobs(), L.layer->ExactNumTopBlobs());
+        while ((int)L.top.size() < need) {
+          owned_.emplace_back(new Blob<float>());
+          L.top.push_back(owned_.back().get());
+          L.top_names.push_back("(automatic)");
+        }
+      }
+      L.layer->SetUp(L.bottom, L.top);
+      share_params(L);
+      L.runnable = true;
+      ++n;
+    }
+    return n;
+  }
+  float Forward() {
+    float loss = 0;
+    for (PathNetLayer& L : layers_) if (L.runnable) loss += L.layer->Forward(L.bottom, L.top);
+    return loss;
+  }
+  void Backward() {
+    for (size_t i = layers_.size(); i-- > 0;) {
+      PathNetLayer& L = layers_[i];
+      if (!L.runnable) continue;
+      const string t = L.param.type();
+      if (t == "HDF5Data" || t == "MAP" || t == "MRR" || t == "AUC" || t == "RankAccuracy") continue;   // no backward
+      vector<bool> pd(L.bottom.size(), true);
+      for (size_t b = 0; b < L.bottom.size(); ++b) {
+        if (t == "Embed") pd[b] = false;                             // indices (embed_layer.cpp:156)
+        if (t == "PairRankLoss" && b == 2) pd[b] = false;            // labels (pair_rank_loss_layer.cpp:58-61)
+        if (produced_by_data_.count(L.bottom_names[b])) pd[b] = false;
+      }
+      L.layer->Backward(L.top, pd, L.bottom);
+    }
+  }
+  Blob<float>* find_blob(const string& n) { auto it = blobs_.find(n); return it == blobs_.end() ? nullptr : it->second; }
+  vector<PathNetLayer>& layers() { return layers_; }
+  const vector<string>& blob_names() const { return blob_order_; }
+  const string& name() const { return name_; }
+ private:
+  bool included(const LayerParameter& lp) const {
+    // net.cpp:272-296 FilterNet: no include rules = included unless an exclude rule matches; with include
+    // rules, included iff one matches
+    auto matches = [&](int rule) { return rule < 0 || rule == phase_; };
+    if (lp.include_phase_.empty()) {
+      for (int r : lp.exclude_phase_) if (matches(r)) return false;
+      return true;
+    }
+    for (int r : lp.include_phase_) if (matches(r)) return true;
+    return false;
+  }
+  Blob<float>* blob(const string& n, bool create) {
+    auto it = blobs_.find(n);
+    if (it != blobs_.end()) return it->second;
+    if (!create) return nullptr;
+    owned_.emplace_back(new Blob<float>());
+    blobs_[n] = owned_.back().get();
+    blob_order_.push_back(n);
+    return owned_.back().get();
+  }
+  void share_params(PathNetLayer& L) {
+    const string t = L.param.type();
+    if (t == "HDF5Data") for (const string& tn : L.top_names) produced_by_data_.insert(tn);
+    auto& blobs = L.layer->blobs();
+    for (size_t i = 0; i < L.param.param_.size() && i < blobs.size(); ++i) {
+      const string& pn = L.param.param_[i].name;
+      if (pn.empty()) continue;
+      auto it = shared_params_.find(pn);
+      if (it == shared_params_.end()) { shared_params_[pn] = blobs[i]; continue; }
+      CHECK_EQ(it->second->count(), blobs[i]->count()) << "Shared parameter '" << pn << "' has mismatched sizes";
+      blobs[i] = it->second;                                         // ShareData + ShareDiff with the owner
+    }
+  }
+  string name_;
+  int phase_;
+  vector<PathNetLayer> layers_;
+  std::map<string, Blob<float>*> blobs_;
+  vector<string> blob_order_;
+  vector<std::unique_ptr<Blob<float> > > owned_;
+  std::map<string, shared_ptr<Blob<float> > > shared_params_;
+  std::set<string> produced_by_data_;
+};
+}  // namespace caffe
+
 // ================================== C handle API =============================
 struct mms_blob {
   caffe::Blob<float>* b;
@@ -1139,6 +1343,11 @@ struct mms_blob {
 struct mms_layer {
   std::shared_ptr<caffe::Layer<float> > l;
   std::vector<std::unique_ptr<mms_blob> > param_handles;
+};
+struct mms_net {
+  std::unique_ptr<caffe::PathNet> net;
+  std::map<std::string, std::unique_ptr<mms_blob> > blob_handles;
+  std::vector<std::unique_ptr<mms_layer> > layer_handles;
 };
 
 namespace {
@@ -1207,6 +1416,45 @@ mms_blob_t* mms_layer_param_blob(mms_layer_t* l, int i) {
 }
 void mms_layer_set_param_propagate_down(mms_layer_t* l, int i, int v) { l->l->set_param_propagate_down(i, v != 0); }
 int mms_layer_set_option(mms_layer_t* l, const char* key, int value) { return (key && l->l->SetOption(key, value)) ? 0 : 1; }
+// ---- whole nets ----
+mms_net_t* mms_net_create(const char* prototxt, int phase, char* err, int err_len) {
+  caffe::NetParameter np;
+  std::string e;
+  if (!caffe::ReadNetParameterFromText(prototxt ? prototxt : "", &np, &e)) {
+    if (err && err_len > 0) std::snprintf(err, err_len, "%s", e.c_str());
+    return nullptr;
+  }
+  mms_net_t* h = new mms_net;
+  h->net.reset(new caffe::PathNet(np, phase ? 1 : 0));
+  h->layer_handles.resize(h->net->layers().size());
+  return h;
+}
+void mms_net_destroy(mms_net_t* n) { delete n; }
+const char* mms_net_name(const mms_net_t* n) { return n->net->name().c_str(); }
+int mms_net_num_layers(const mms_net_t* n) { return (int)n->net->layers().size(); }
+const char* mms_net_layer_name(const mms_net_t* n, int i) { return n->net->layers()[i].param.name().c_str(); }
+const char* mms_net_layer_type(const mms_net_t* n, int i) { return n->net->layers()[i].param.type().c_str(); }
+int mms_net_layer_supported(const mms_net_t* n, int i) { return n->net->layers()[i].layer ? 1 : 0; }
+int mms_net_layer_runnable(const mms_net_t* n, int i) { return n->net->layers()[i].runnable ? 1 : 0; }
+const char* mms_net_layer_why_not(const mms_net_t* n, int i) { return n->net->layers()[i].why_not.c_str(); }
+mms_layer_t* mms_net_layer(mms_net_t* n, int i) {
+  if (i < 0 || i >= (int)n->net->layers().size() || !n->net->layers()[i].layer) return nullptr;
+  if (!n->layer_handles[i]) { n->layer_handles[i].reset(new mms_layer); n->layer_handles[i]->l = n->net->layers()[i].layer; }
+  return n->layer_handles[i].get();
+}
+int mms_net_num_blobs(const mms_net_t* n) { return (int)n->net->blob_names().size(); }
+const char* mms_net_blob_name(const mms_net_t* n, int i) { return n->net->blob_names()[i].c_str(); }
+mms_blob_t* mms_net_blob(mms_net_t* n, const char* name) {
+  caffe::Blob<float>* b = name ? n->net->find_blob(name) : nullptr;
+  if (!b) return nullptr;
+  auto& h = n->blob_handles[name];
+  if (!h) h.reset(new mms_blob{b, nullptr, false});
+  return h.get();
+}
+int mms_net_setup(mms_net_t* n) { return n->net->SetUp(); }
+float mms_net_forward(mms_net_t* n) { return n->net->Forward(); }
+void mms_net_backward(mms_net_t* n) { n->net->Backward(); }
+
 void mms_caffe_set_mode(int gpu) { caffe::Caffe::set_mode(gpu ? caffe::Caffe::GPU : caffe::Caffe::CPU); }
 void mms_caffe_set_random_seed(unsigned seed) { caffe::caffe_set_random_seed(seed); }
 const char* mms_layer_registry_types(void) {

@@ -43,6 +43,22 @@ _SIGNATURES = {
     "mms_layer_param_blob": (_vp, [_vp, _i]),
     "mms_layer_set_param_propagate_down": (None, [_vp, _i, _i]),
     "mms_layer_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "mms_net_create": (_vp, [C.c_char_p, _i, C.c_char_p, _i]),
+    "mms_net_destroy": (None, [_vp]),
+    "mms_net_name": (C.c_char_p, [_vp]),
+    "mms_net_num_layers": (_i, [_vp]),
+    "mms_net_layer_name": (C.c_char_p, [_vp, _i]),
+    "mms_net_layer_type": (C.c_char_p, [_vp, _i]),
+    "mms_net_layer_supported": (_i, [_vp, _i]),
+    "mms_net_layer_runnable": (_i, [_vp, _i]),
+    "mms_net_layer_why_not": (C.c_char_p, [_vp, _i]),
+    "mms_net_layer": (_vp, [_vp, _i]),
+    "mms_net_num_blobs": (_i, [_vp]),
+    "mms_net_blob_name": (C.c_char_p, [_vp, _i]),
+    "mms_net_blob": (_vp, [_vp, C.c_char_p]),
+    "mms_net_setup": (_i, [_vp]),
+    "mms_net_forward": (C.c_float, [_vp]),
+    "mms_net_backward": (None, [_vp]),
     "mms_caffe_set_mode": (None, [_i]),
     "mms_caffe_set_random_seed": (None, [C.c_uint]),
     "mms_layer_registry_types": (C.c_char_p, []),
@@ -202,9 +218,9 @@ class Layer:
             raise ValueError("prototxt: " + err.value.decode())
 
     def __del__(self):
-        if getattr(self, "_h", None) and _lib is not None:
+        if getattr(self, "_h", None) and _lib is not None and not getattr(self, "_borrowed", False):
             _lib.mms_layer_destroy(self._h)
-            self._h = None
+        self._h = None
 
     @property
     def type(self):
@@ -238,6 +254,68 @@ class Layer:
         """Per-layer switch of this implementation (include/mms_layer.h: mms_layer_set_option)."""
         if lib().mms_layer_set_option(self._h, key.encode(), int(value)) != 0:
             raise KeyError("%s layer has no option %r" % (self.type, key))
+
+
+class Net:
+    """A generated net file (NetParameter text), unmodified: the layers this library implements are
+    instantiated and wired by blob name, the others are listed and skipped (include/mms_layer.h: mms_net_*).
+    phase: "TRAIN" or "TEST"."""
+
+    def __init__(self, prototxt, phase="TEST"):
+        err = C.create_string_buffer(512)
+        self._h = lib().mms_net_create(prototxt.encode(), 1 if phase in ("TEST", 1) else 0, err, 512)
+        if not self._h:
+            raise ValueError("net prototxt: " + err.value.decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.mms_net_destroy(self._h)
+        self._h = None
+
+    @property
+    def name(self):
+        return lib().mms_net_name(self._h).decode()
+
+    @property
+    def layers(self):
+        """[(name, type, supported, runnable, why_not)] in file order, after phase filtering."""
+        l, h = lib(), self._h
+        return [(l.mms_net_layer_name(h, i).decode(), l.mms_net_layer_type(h, i).decode(),
+                 bool(l.mms_net_layer_supported(h, i)), bool(l.mms_net_layer_runnable(h, i)),
+                 l.mms_net_layer_why_not(h, i).decode()) for i in range(l.mms_net_num_layers(h))]
+
+    @property
+    def blob_names(self):
+        return [lib().mms_net_blob_name(self._h, i).decode() for i in range(lib().mms_net_num_blobs(self._h))]
+
+    def blob(self, name):
+        b = lib().mms_net_blob(self._h, name.encode())
+        if not b:
+            raise KeyError(name)
+        bl = Blob(_handle=b)
+        bl._keep = self                 # the net owns the blob
+        return bl
+
+    def layer(self, name):
+        for i, (n, _, sup, _, _) in enumerate(self.layers):
+            if n == name:
+                if not sup:
+                    raise KeyError("%s is not a layer type of this library" % name)
+                lay = Layer.__new__(Layer)
+                lay._h = lib().mms_net_layer(self._h, i)
+                lay._borrowed = True
+                lay._keep = self
+                return lay
+        raise KeyError(name)
+
+    def SetUp(self):
+        return lib().mms_net_setup(self._h)
+
+    def Forward(self):
+        return float(lib().mms_net_forward(self._h))
+
+    def Backward(self):
+        lib().mms_net_backward(self._h)
 
 
 def _make(type_name, param_field, name=None, loss_weight=None, top=None, **kwargs):

@@ -1,0 +1,142 @@
+"""a generated multi-layer net file runs unmodified.  The fixture is a hand-written
+NetParameter text with network_v4's field values (examples/trec_qa_w2v_mms/do_trec_qa_clean.py:452-496; schema
+src/caffe/proto/caffe.proto:63-110, 310-416).  CPU part: parsing, phase filtering, what is instantiated and what is
+listed as skipped.  GPU part: the layers of the path run end to end out of the file -- HDF5Data -> Embed x2 (shared
+table) -> SimCross (bilinear, M = 4, bias) forward and backward, and MRR / MAP / AUC on a host-filled `prob` --
+against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from util import TOL, assert_bitexact, assert_close, rng
+
+FIXTURE = os.path.join(ROOT, "tests", "golden", "network_v4_test.prototxt")
+PATH_TYPES = {"HDF5Data", "Embed", "SimCross", "SimMatrix", "PairRankLoss", "MAP", "MRR", "AUC", "RankAccuracy"}
+
+
+@pytest.fixture(scope="module")
+def L():
+    from mms_answer_selection_amd import layers
+    layers.lib()
+    return layers
+
+
+def test_whole_net_parses_and_lists_every_layer(L):
+    text = open(FIXTURE).read()
+    net = L.Net(text, phase="TEST")
+    assert net.name == "qa-test-net"
+    lay = net.layers
+    names = [n for n, *_ in lay]
+    # the TRAIN-only layer is filtered out in the TEST phase (net.cpp:272-296), everything else is listed in file order
+    assert "train_only_probe" not in names and names[0] == "question" and names[-1] == "auc" and len(lay) == 24
+    for n, t, sup, runnable, why in lay:
+        assert sup == (t in PATH_TYPES), (n, t)
+        assert not runnable                                  # nothing has been set up yet
+    skipped = sorted({t for _, t, sup, _, _ in lay if not sup})
+    assert skipped == ["BN", "Concat", "Convolution", "Dropout", "Flatten", "InnerProduct", "Pooling", "Softmax",
+                       "SoftmaxWithLoss", "TanH"]
+    # in-place tops share their bottom's blob; every named blob exists exactly once
+    bl = net.blob_names
+    assert len(bl) == len(set(bl)) and bl.count("pool0") == 1 and {"question", "w2v_q", "sim_cross", "prob", "map"} <= set(bl)
+    train = L.Net(text, phase="TRAIN")
+    assert [n for n, *_ in train.layers][-1] == "train_only_probe"
+
+
+def test_net_reader_rejects_malformed_text(L):
+    for bad in ("layer { name: \"x\" }",                          # no type
+                "layer { name: \"x\" type: \"SimCross\" sim_cross_param { no_such_field: 1 } }",
+                "layer { type: \"SimCross\" bottom: }",
+                "no_such_net_field: 3",
+                "layer { type: \"SimCross\" "):
+        with pytest.raises(ValueError):
+            L.Net(bad)
+
+
+@pytest.mark.gpu
+def test_network_v4_path_layers_run_from_the_net_file(L, oracle, tmp_path):
+    B, Wd, D, V, groups = 12, 40, 50, 64, 3
+    r = rng(44)
+    question = r.integers(0, V, (2 * B, Wd)).astype(np.float64)
+    answer = r.integers(0, V, (2 * B, Wd)).astype(np.float64)
+    label = (r.uniform(size=(2 * B,)) < 0.3).astype(np.float64)
+    label[:3] = [1, 0, 1]
+    group = np.sort(r.integers(0, groups, 2 * B)).astype(np.float64)
+    overlap = r.uniform(size=(2 * B, 2))
+    h5 = tmp_path / "test.h5"
+    L.write_h5(h5, dict(question=question, answer=answer, label=label, group=group, overlap_feat=overlap))
+    src = tmp_path / "source.txt"
+    src.write_text(str(h5) + "\n")
+    net = L.Net(open(FIXTURE).read().replace("__SOURCE__", str(src)), phase="TEST")
+    L.set_mode_gpu()
+    L.set_random_seed(1701)
+
+    # `prob` is produced by layers outside the library (fc2 -> Softmax): the host supplies it
+    s = r.uniform(0.05, 0.95, B).astype(np.float32)
+    prob = np.stack([1 - s, s], 1).astype(np.float32)
+    pb = net.blob("prob")
+    pb.reshape(B, 2)
+    pb.data[...] = prob
+    n_run = net.SetUp()
+    state = {n: (run, why) for n, _, _, run, why in net.layers}
+    for n in ("question", "w2v_q", "w2v_a", "sim_cross", "mrr", "map", "auc"):
+        assert state[n][0], (n, state[n][1])
+    assert n_run == 7
+    assert not state["conv0"][0] and "not implemented" in state["conv0"][1]
+
+    # the two Embed layers share `w2v-weights` / `w2v-bias` by name; SimCross's W and bias start at zero
+    # (constant filler, do_trec_qa_clean.py:468 gives none): give them values so the products mean something
+    eq, ea, sc = net.layer("w2v_q"), net.layer("w2v_a"), net.layer("sim_cross")
+    table = eq.blobs[0].data.copy()
+    assert table.shape == (V, D) and np.abs(table).max() <= 0.08 and table.std() > 0.03
+    eq.blobs[0].data[3, :] = 0.5
+    assert (ea.blobs[0].data[3, :] == 0.5).all(), "the answer Embed reads the SAME table"
+    table = eq.blobs[0].data.copy()
+    Wm = r.uniform(-0.08, 0.08, sc.blobs[0].shape).astype(np.float32)
+    bias = r.uniform(-0.1, 0.1, sc.blobs[1].shape).astype(np.float32)
+    assert Wm.shape == (4, D, D) and bias.shape == (4, Wd, Wd)
+    sc.blobs[0].data[...] = Wm
+    sc.blobs[1].data[...] = bias
+
+    loss = net.Forward()
+    assert loss == 0.0                                       # no loss layer of the library in this net
+    # batch 0 of the file, in order (shuffle: false)
+    assert_bitexact(net.blob("question").data, question[:B].astype(np.float32))
+    assert_bitexact(net.blob("group").data.ravel(), group[:B].astype(np.float32))
+    q_ref = table[question[:B].astype(int)]                  # bias is the constant 0
+    a_ref = table[answer[:B].astype(int)]
+    assert_bitexact(net.blob("w2v_q").data, q_ref)
+    assert_bitexact(net.blob("w2v_a").data, a_ref)
+    top_ref, _, _ = oracle.simcross_forward(2, q_ref, a_ref, Wm, bias)
+    assert net.blob("sim_cross").shape == (B, 4, Wd, Wd)
+    assert_close(net.blob("sim_cross").data, top_ref, TOL, "sim_cross")
+    # the evaluation layers of the TEST net on the host-filled prob
+    lab32, grp32 = label[:B].astype(np.float32), group[:B].astype(np.float32)
+    m_ref, _ = oracle.map_score(prob, lab32, grp32)
+    rr_ref, _ = oracle.mrr_score(prob, lab32, grp32)
+    auc_ref = oracle.auc_score(prob, lab32)
+    same = lambda x, y: np.float32(x).view(np.uint32) == np.float32(y).view(np.uint32)
+    assert same(net.blob("map").data.ravel()[0], m_ref)
+    assert same(net.blob("mrr").data.ravel()[0], rr_ref)
+    assert same(net.blob("auc").data.ravel()[0], auc_ref)
+
+    # all forwards, then all backwards (net.cpp:581-591): dW / dbias of SimCross and the shared table's gradient
+    dT = r.standard_normal(top_ref.shape).astype(np.float32)
+    net.blob("sim_cross").diff[...] = dT
+    for b in (sc.blobs[0], sc.blobs[1], eq.blobs[0], eq.blobs[1]):
+        b.diff[...] = 0                                      # Net::ClearParamDiffs (net.cpp:923-941)
+    net.Backward()
+    dq_ref, da_ref, dW_ref, db_ref = oracle.simcross_backward(2, q_ref, a_ref, top_ref, dT, W=Wm, bias_term=True)
+    assert_close(sc.blobs[0].diff, dW_ref, TOL, "dW")
+    assert_close(sc.blobs[1].diff, db_ref, TOL, "dbias")
+    assert_close(net.blob("w2v_q").diff, dq_ref, TOL, "dq")
+    assert_close(net.blob("w2v_a").diff, da_ref, TOL, "da")
+    # both Embed layers scatter into the ONE shared table diff (embed_layer.cpp:155-180)
+    dtab = np.zeros_like(table)
+    np.add.at(dtab, question[:B].astype(int).ravel(), dq_ref.reshape(-1, D))
+    np.add.at(dtab, answer[:B].astype(int).ravel(), da_ref.reshape(-1, D))
+    assert_close(eq.blobs[0].diff, dtab, 2e-4, "shared table diff")
+    # the next Forward serves the file's second batch
+    net.Forward()
+    assert_bitexact(net.blob("question").data, question[B:].astype(np.float32))
