@@ -285,6 +285,14 @@ int mms_rank_auc_f32(int n, int dim, int fixed_axis, const float* prob, const fl
                      int has_ignore_label, int ignore_label, float* auc_out,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same layer for any label axis: prob (outer, channels, inner) -- bottom[0] with `axis` as its label axis,
+ * outer = count(0, axis), inner = count(axis + 1) -- and label (outer, inner); item (o, j) scores
+ * prob[o*channels*inner + fixed_axis*inner + j] (auc_layer.cpp:66-77).  Items whose label equals ignore_label are
+ * skipped when has_ignore_label (:69-71).  Workspace: mms_rank_workspace_bytes(outer * inner). */
+int mms_rank_auc_nd_f32(int outer, int channels, int inner, int fixed_axis, const float* prob,
+                        const float* label, int has_ignore_label, int ignore_label, float* auc_out,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* Replaces RankAccuracyLayer<float>::Forward_cpu
  * (src/caffe/layers/rank_accuracy_layer.cpp:36-50): mean of [label*(a-b) > 0]. */
 int mms_rank_accuracy_f32(int count, const float* a, const float* b, const float* label,

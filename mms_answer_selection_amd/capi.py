@@ -7,6 +7,7 @@ missing or a tensor is not on the GPU the call raises.
 import ctypes as C
 import os
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -60,6 +61,7 @@ _SIGNATURES = {
     "mms_rank_workspace_bytes": (_sz, [_i]),
     "mms_rank_map_mrr_f32": (_i, [_i, _i] + [_vp] * 7 + [_sz, _vp]),
     "mms_rank_auc_f32": (_i, [_i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "mms_rank_auc_nd_f32": (_i, [_i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "mms_rank_accuracy_f32": (_i, [_i] + [_vp] * 5 + [_sz, _vp]),
 }
 
@@ -116,15 +118,22 @@ class Workspace:
 
     def __init__(self):
         self.buf = None
+        self._retired = []          # superseded buffers stay alive: a captured hipGraph or work still queued on
+                                    # another stream may hold their address (they are freed with the Workspace)
 
     def get(self, nbytes, device):
         if nbytes == 0:
             return None, 0
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            if self.buf is not None:
+                self._retired.append(self.buf)
             self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         return self.buf.data_ptr(), self.buf.numel()
 
 
+# Calls that are not given a Workspace share this one.  It only grows, and what it outgrows is retired, not freed;
+# callers that capture graphs or use several streams should still pass their own (`ws=`): the library keeps
+# intermediates in it BETWEEN its own launches of one call, so two calls in flight must not share a workspace.
 _default_ws = Workspace()
 
 
@@ -258,6 +267,22 @@ def rank_auc(prob, label, fixed_axis=1, ignore_label=None, ws=None):
         n, int(prob.shape[1]), int(fixed_axis), _ptr(prob, "prob"), _ptr(label, "label"),
         int(ignore_label is not None), int(ignore_label or 0), out.data_ptr(), wsp, wsb, _stream()),
         "mms_rank_auc_f32")
+    return out.cpu().numpy()[0]
+
+
+def rank_auc_nd(prob, label, axis=1, fixed_axis=1, ignore_label=None, ws=None):
+    """AUC layer for any label axis: prob (..., C, ...) with `axis` the class axis, label of the remaining shape."""
+    shape = tuple(prob.shape)
+    axis = axis % len(shape)
+    outer = int(np.prod(shape[:axis])) if axis else 1
+    inner = int(np.prod(shape[axis + 1:])) if axis + 1 < len(shape) else 1
+    n = outer * inner
+    wsp, wsb = (ws or _default_ws).get(lib().mms_rank_workspace_bytes(n), prob.device)
+    out = torch.empty(1, dtype=torch.float32, device=prob.device)
+    check(lib().mms_rank_auc_nd_f32(
+        outer, int(shape[axis]), inner, int(fixed_axis), _ptr(prob, "prob"), _ptr(label, "label"),
+        int(ignore_label is not None), int(ignore_label or 0), out.data_ptr(), wsp, wsb, _stream()),
+        "mms_rank_auc_nd_f32")
     return out.cpu().numpy()[0]
 
 

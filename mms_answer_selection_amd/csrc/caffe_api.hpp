@@ -68,6 +68,7 @@ struct NullStream {
 #define CHECK_GT(a, b) CHECK_OP(a, b, >)
 #define LOG_FATAL MMS_FATAL("")
 #define LOG_INFO ::caffe::NullStream()
+#define LOG(severity) LOG_##severity   // glog spelling: LOG(FATAL) << ..., LOG(INFO) << ...
 #define HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) MMS_FATAL("HIP: ") << hipGetErrorString(e_) << " in " #expr; } while (0)
 #define NOT_IMPLEMENTED MMS_FATAL("Not Implemented Yet")
 

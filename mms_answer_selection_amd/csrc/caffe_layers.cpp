@@ -703,18 +703,17 @@ class AUCLayer : public RankMetricLayerBase<Dtype> {
     outer_num_ = bottom[0]->count(0, label_axis_);
     inner_num_ = bottom[0]->count(label_axis_ + 1);
     CHECK_EQ(outer_num_ * inner_num_, bottom[1]->count()) << "Number of labels must match number of predictions";
-    CHECK_EQ(inner_num_, 1) << "AUC on the GPU is provided for inner_num == 1 (prob (N,C)), as the driver uses it";
     top[0]->Reshape(vector<int>());
-    this->size_workspace(outer_num_);
+    this->size_workspace(outer_num_ * inner_num_);
   }
  protected:
   void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
-    mms_check(mms_rank_auc_f32(outer_num_, bottom[0]->count() / outer_num_, fixed_axis_,
-                               bottom[0]->gpu_data(), bottom[1]->gpu_data(), has_ignore_label_,
-                               ignore_label_, top[0]->mutable_gpu_data(),
-                               this->workspace_.mutable_gpu_data(),
-                               (size_t)this->workspace_.count() * sizeof(Dtype), nullptr),
-              "mms_rank_auc_f32");
+    mms_check(mms_rank_auc_nd_f32(outer_num_, bottom[0]->shape(label_axis_), inner_num_, fixed_axis_,
+                                  bottom[0]->gpu_data(), bottom[1]->gpu_data(), has_ignore_label_,
+                                  ignore_label_, top[0]->mutable_gpu_data(),
+                                  this->workspace_.mutable_gpu_data(),
+                                  (size_t)this->workspace_.count() * sizeof(Dtype), nullptr),
+              "mms_rank_auc_nd_f32");
   }
   int fixed_axis_ = 1, label_axis_ = 1, outer_num_ = 0, inner_num_ = 1, ignore_label_ = 0;
   bool has_ignore_label_ = false;

@@ -51,7 +51,7 @@ size_t rank_workspace_bytes(int n);
 int rank_map_mrr(int n, int fixed_axis, const float* prob, const float* label, const float* group,
                  float* map_out, float* mrr_out, int* effective, void* ws, size_t ws_bytes,
                  hipStream_t s);
-int rank_auc(int n, int dim, int fixed_axis, const float* prob, const float* label, int has_ignore,
+int rank_auc(int n, int dim, int fixed_axis, int inner, const float* prob, const float* label, int has_ignore,
              int ignore_label, float* auc_out, void* ws, size_t ws_bytes, hipStream_t s);
 int rank_accuracy(int count, const float* a, const float* b, const float* label, float* out,
                   void* ws, size_t ws_bytes, hipStream_t s);
@@ -344,8 +344,19 @@ int mms_rank_auc_f32(int n, int dim, int fixed_axis, const float* prob, const fl
       (long long)n * dim > 0x7fffffffLL)
     return MMS_ERR_INVALID_ARG;
   if (!prob || !label || !auc_out) return MMS_ERR_INVALID_ARG;
-  return rank_auc(n, dim, fixed_axis, prob, label, has_ignore_label, ignore_label, auc_out,
+  return rank_auc(n, dim, fixed_axis, 1, prob, label, has_ignore_label, ignore_label, auc_out,
                   workspace, workspace_bytes, as_stream(stream));
+}
+
+int mms_rank_auc_nd_f32(int outer, int channels, int inner, int fixed_axis, const float* prob,
+                        const float* label, int has_ignore_label, int ignore_label, float* auc_out,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (outer <= 0 || channels <= 0 || inner <= 0 || fixed_axis < 0 || fixed_axis >= channels ||
+      (long long)outer * channels * inner > 0x7fffffffLL)
+    return MMS_ERR_INVALID_ARG;
+  if (!prob || !label || !auc_out) return MMS_ERR_INVALID_ARG;
+  return rank_auc(outer * inner, channels * inner, fixed_axis, inner, prob, label, has_ignore_label, ignore_label,
+                  auc_out, workspace, workspace_bytes, as_stream(stream));
 }
 
 int mms_rank_accuracy_f32(int count, const float* a, const float* b, const float* label,

@@ -32,7 +32,9 @@ __device__ __forceinline__ unsigned desc_bits(float s) {
   return ~u;                                         // descending
 }
 
-__global__ __launch_bounds__(256) void rank_keys_kernel(int n, int stride, int offset,
+// item i = (outer o, inner j) = (i / inner, i % inner); its score is prob[o*stride + offset*inner + j]
+// (auc_layer.cpp:75-76; inner = 1 for MAP / MRR and for prob (N, C))
+__global__ __launch_bounds__(256) void rank_keys_kernel(int n, int stride, int offset, int inner,
                                                         const float* __restrict__ prob,
                                                         const float* __restrict__ group,
                                                         unsigned long long* __restrict__ keys,
@@ -40,7 +42,8 @@ __global__ __launch_bounds__(256) void rank_keys_kernel(int n, int stride, int o
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const unsigned g = group ? (unsigned)((int)group[i]) + 0x80000000u : 0u;   // map<int,...> key order
-  keys[i] = ((unsigned long long)g << 32) | desc_bits(prob[(size_t)i * stride + offset]);
+  const int o = i / inner, j = i - o * inner;
+  keys[i] = ((unsigned long long)g << 32) | desc_bits(prob[(size_t)o * stride + (size_t)offset * inner + j]);
   vals[i] = (unsigned)i;
 }
 
@@ -257,7 +260,7 @@ int rank_map_mrr(int n, int fixed_axis, const float* prob, const float* label, c
   char* base = static_cast<char*>(ws);
   const unsigned grid = (unsigned)((n + 255) / 256);
   // score of item i: prob[i*(fixed_axis+1) + fixed_axis]  (map_layer.cpp:50, mrr_layer.cpp:49)
-  hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(256), 0, s, n, fixed_axis + 1, fixed_axis,
+  hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(256), 0, s, n, fixed_axis + 1, fixed_axis, 1,
                      prob, group, reinterpret_cast<unsigned long long*>(base + lay.keys0),
                      reinterpret_cast<unsigned*>(base + lay.vals0));
   int rc = sort_pairs(lay, base, ws_bytes, n, 64u, s);
@@ -273,14 +276,15 @@ int rank_map_mrr(int n, int fixed_axis, const float* prob, const float* label, c
   return launch_status();
 }
 
-int rank_auc(int n, int dim, int fixed_axis, const float* prob, const float* label, int has_ignore,
+// n = outer * inner items; dim = channels * inner floats per outer index
+int rank_auc(int n, int dim, int fixed_axis, int inner, const float* prob, const float* label, int has_ignore,
              int ignore_label, float* auc_out, void* ws, size_t ws_bytes, hipStream_t s) {
   const RankWs lay = rank_ws(n);
   if (!ws || ws_bytes < lay.temp) return MMS_ERR_WORKSPACE;
   char* base = static_cast<char*>(ws);
   const unsigned grid = (unsigned)((n + 255) / 256);
   // score of item i: prob[i*dim + fixed_axis]  (auc_layer.cpp:75-76 with inner_num = 1)
-  hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(256), 0, s, n, dim, fixed_axis, prob,
+  hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(256), 0, s, n, dim, fixed_axis, inner, prob,
                      static_cast<const float*>(nullptr),
                      reinterpret_cast<unsigned long long*>(base + lay.keys0),
                      reinterpret_cast<unsigned*>(base + lay.vals0));

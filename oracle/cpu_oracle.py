@@ -200,6 +200,18 @@ def auc_score(prob, label, fixed_axis=1):
         int(label.size), int(prob.shape[1]), int(fixed_axis), _p(prob), _p(label)))
 
 
+def auc_score_nd(prob, label, axis=1, fixed_axis=1, ignore_label=None):
+    """prob with its class axis at `axis`, label of the remaining shape.  auc_layer.cpp:47-136, general indexing."""
+    prob, label = _c(prob, np.float32), _c(label, np.float32)
+    axis = axis % prob.ndim
+    outer = int(np.prod(prob.shape[:axis])) if axis else 1
+    inner = int(np.prod(prob.shape[axis + 1:])) if axis + 1 < prob.ndim else 1
+    f = lib().oracle_auc_nd_f32
+    f.restype = C.c_float
+    return np.float32(f(outer, int(prob.shape[axis]), inner, int(fixed_axis), _p(prob), _p(label),
+                        int(ignore_label is not None), int(ignore_label or 0)))
+
+
 def time_simcross_fwd_bwd(mode, q, a, top_diff, W=None, bias=None, iters=1):
     """Seconds for `iters` forward+backward passes, one thread (cpu_baseline leg)."""
     dt = np.float32

@@ -105,9 +105,42 @@ Dtype auc_impl(int n, int dim, int fixed_axis, const Dtype* prob,
   if (high > 0) return auc_value / high / (count - high);
   return 0;
 }
+// auc_layer.cpp:47-136 with its general indexing: items (i, j), i < outer, j < inner; score
+// prob[i*dim + fixed_axis*inner + j] with dim = channels*inner (:75-76), label label[i*inner + j] (:67-68),
+// ignore_label items skipped before they are counted (:69-71).
+template <typename Dtype>
+Dtype auc_nd_impl(int outer, int channels, int inner, int fixed_axis, const Dtype* prob, const Dtype* label,
+                  int has_ignore, int ignore_label) {
+  Dtype auc_value = 0;
+  int high = 0, count = 0;
+  const int dim = channels * inner;
+  std::vector<std::pair<Dtype, int> > v;
+  for (int i = 0; i < outer; ++i) {
+    for (int j = 0; j < inner; ++j) {
+      const int label_value = static_cast<int>(label[(size_t)i * inner + j]);
+      if (has_ignore && label_value == ignore_label) continue;
+      v.push_back(std::make_pair(prob[(size_t)i * dim + (size_t)fixed_axis * inner + j], label_value));
+      ++count;
+    }
+  }
+  std::sort(v.begin(), v.end(),
+            [](const std::pair<Dtype, int>& l, const std::pair<Dtype, int>& r) {
+              return score_desc(std::pair<float, int>(l), std::pair<float, int>(r));
+            });
+  for (size_t i = 0; i < v.size(); ++i) {
+    high += v[i].second;
+    auc_value += high * (1 - v[i].second);
+  }
+  if (high > 0) return auc_value / high / (count - high);
+  return 0;
+}
 }  // namespace
 
 extern "C" {
+float oracle_auc_nd_f32(int outer, int channels, int inner, int fixed_axis, const float* prob,
+                        const float* label, int has_ignore, int ignore_label) {
+  return auc_nd_impl<float>(outer, channels, inner, fixed_axis, prob, label, has_ignore, ignore_label);
+}
 float oracle_map_f32(int n, int fixed_axis, const float* prob,
                      const float* label, const float* group, int* effective) {
   return map_impl<float>(n, fixed_axis, prob, label, group, effective);

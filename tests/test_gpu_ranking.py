@@ -60,6 +60,43 @@ def test_map_mrr_auc_random(cfg, oracle, hiplib):
     assert same_bits(capi.rank_auc(dev(prob), dev(label)), oracle.auc_score(prob, label))
 
 
+@pytest.mark.parametrize("shape,axis", [((37, 2), 1), ((11, 2, 5), 1), ((6, 3, 4, 5), 1), ((2, 7, 3), 2), ((3, 4), 0)])
+def test_auc_any_label_axis_and_ignore_label(shape, axis, oracle, hiplib):
+    """AUCLayer with inner_num > 1 and a label axis other than 1 (auc_layer.cpp:26-33, 66-77), plus ignore_label
+    (:69-71): the C ABI and the Layer mirror against the oracle's general indexing, bit for bit."""
+    from mms_answer_selection_amd import capi
+    r = rng(sum(shape) + axis)
+    prob = r.uniform(0.01, 0.99, shape).astype(np.float32)          # distinct scores
+    lshape = shape[:axis] + shape[axis + 1:]
+    label = (r.uniform(size=lshape) < 0.4).astype(np.float32)
+    label.reshape(-1)[:2] = [1, 0]
+    C = shape[axis]
+    for fixed_axis in sorted({0, C - 1}):
+        ref = oracle.auc_score_nd(prob, label, axis=axis, fixed_axis=fixed_axis)
+        got = capi.rank_auc_nd(dev(prob), dev(label), axis=axis, fixed_axis=fixed_axis)
+        assert same_bits(got, ref), (got, ref)
+    # ignore_label: labels of 2 are dropped before counting
+    lab2 = label.copy()
+    lab2.reshape(-1)[3::5] = 2
+    ref = oracle.auc_score_nd(prob, lab2, axis=axis, fixed_axis=C - 1, ignore_label=2)
+    got = capi.rank_auc_nd(dev(prob), dev(lab2), axis=axis, fixed_axis=C - 1, ignore_label=2)
+    assert same_bits(got, ref), (got, ref)
+    # through the Layer mirror (auc_param { axis fixed_axis ignore_label })
+    from mms_answer_selection_amd import layers as L
+    L.lib()
+    L.set_mode_gpu()
+    lay = L.AUC(axis=axis, fixed_axis=C - 1, ignore_label=2)
+    bp, bl, top = L.Blob(shape), L.Blob(lshape), L.Blob()
+    bp.data[...] = prob
+    bl.data[...] = lab2
+    lay.SetUp([bp, bl], [top])
+    lay.Forward([bp, bl], [top])
+    assert same_bits(top.data.reshape(-1)[0], ref)
+    if len(shape) == 2 and axis == 1:                        # the (N, C) case agrees with the original entry point
+        assert same_bits(capi.rank_auc(dev(prob), dev(label), fixed_axis=C - 1),
+                         oracle.auc_score_nd(prob, label, axis=1, fixed_axis=C - 1))
+
+
 def test_skipped_buckets_and_empty_result(oracle, hiplib):
     from mms_answer_selection_amd import capi
     # all-positive and all-negative buckets are skipped (map_layer.cpp:90-92); nothing left -> NaN

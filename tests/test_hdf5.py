@@ -87,6 +87,35 @@ def test_truncation_fuzz_never_crashes(tmp_path):
                 pass
 
 
+def test_crafted_chunk_layouts_are_rejected(tmp_path):
+    """Single-byte edits of the chunked fixture's object headers reach the two guards of the chunk reader -- a
+    chunk rank that differs from the dataspace's, a chunk larger than the file could hold -- and are turned into
+    errors (never an out-of-bounds index or a huge allocation)."""
+    raw = bytearray(open(F2, "rb").read())
+    seen = set()
+    p = tmp_path / "crafted.h5"
+    for pos in range(8, min(len(raw), 6000)):
+        for val in {(raw[pos] + 1) & 0xFF, (raw[pos] - 1) & 0xFF, 0xFF}:
+            b = bytearray(raw)
+            b[pos] = val
+            p.write_bytes(bytes(b))
+            try:
+                g = L.H5File(p)
+                for k in g.keys():
+                    try:
+                        g[k]
+                    except (IOError, KeyError, ValueError) as e:
+                        m = str(e)
+                        for tag in ("chunk rank differs", "implausible chunk size", "chunk larger than its file",
+                                    "zero chunk dimension", "unexpected size"):
+                            if tag in m:
+                                seen.add(tag)
+            except (IOError, UnicodeDecodeError):
+                pass
+    assert "chunk rank differs" in seen, seen
+    assert seen & {"implausible chunk size", "chunk larger than its file", "unexpected size"}, seen
+
+
 def test_writer_round_trip_driver_format(tmp_path):
     """do_trec_qa_clean.py:228-246: float64 question/answer/label/group/overlap_feat per file."""
     r = np.random.default_rng(5)
