@@ -101,15 +101,18 @@ def shard_loss_weight(loss_weight, n_local, n_total):
     batch (pair_rank_loss_layer.cpp:62-64).  The C ABI divides by the count it is given, which on a shard is
     the local count, so an unscaled call would return gradients world_size times too large.  Passing
     loss_weight * n_local / n_total restores the reference's scale: (w * n_local / n_total) / n_local = w / n_total.
-    The shard's LOSS output is then (w * n_local / n_total) * mean_local; summing it over ranks
-    (all_reduce_shard_losses) gives w * mean over the whole batch."""
+    The loss OUTPUT of those calls is the unweighted mean over the shard; all_reduce_shard_losses() turns the
+    per-shard means into the batch loss."""
     if n_total <= 0 or n_local < 0 or n_local > n_total:
         raise ValueError("shard of %d pairs out of %d" % (n_local, n_total))
     return float(loss_weight) * float(n_local) / float(n_total)
 
 
-def all_reduce_shard_losses(local_loss, group=None):
-    """Sum of the per-shard losses produced with shard_loss_weight(): the loss of the whole batch."""
-    t = local_loss.clone()
+def all_reduce_shard_losses(local_mean_loss, n_local, n_total, loss_weight=1.0, group=None):
+    """The loss of the WHOLE batch from the per-shard losses.  The C ABI's loss outputs (mms_pairrank_forward_f32,
+    mms_triplet_euclid_step_f32) are the UNWEIGHTED mean over the elements they were given, so a shard's share of
+    the batch mean is n_local / n_total of it; the Layer's loss weight multiplies the result
+    (layer.hpp:462-481)."""
+    t = local_mean_loss.clone() * (float(loss_weight) * float(n_local) / float(n_total))
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t

@@ -72,7 +72,7 @@ def bilinear_and_loss():
     ok_t = rel(mine["dq"], full["dq"][lo:hi]) < 2e-6 and rel(mine["da_pos"], full["da_pos"][lo:hi]) < 2e-6
     unscaled = run(slice(lo, hi), 1.0)                # the hazard: world_size times too large
     ok_t = ok_t and rel(unscaled["dq"], full["dq"][lo:hi]) > 0.5
-    tot = sharded.all_reduce_shard_losses(mine["loss"].cpu())
+    tot = sharded.all_reduce_shard_losses(mine["loss"].cpu(), hi - lo, N)
     ok_t = ok_t and abs(float(tot) - float(full["loss"].cpu())) < 1e-5
     if rank == 0:
         print("sharded triplet step with shard_loss_weight == unsharded: %s" % ok_t)

@@ -104,14 +104,14 @@ def _loss_worker(rank, world, port, n, ret):
             _, dq_bad, _, _, _ = chain(q[lo:hi], ap[lo:hi], an[lo:hi], y[lo:hi], w)
             if np.abs(dq_ref[lo:hi]).max() > 0 and (hi - lo) != n:
                 ok[1] = not np.allclose(dq_bad, dq_ref[lo:hi], **tol)
-            lt = torch.tensor([float(loss) * tw])
+            lt = torch.tensor([float(loss)])
         else:
             dW = np.zeros_like(Wt)
             lt = torch.zeros(1)
         dWt = torch.from_numpy(np.ascontiguousarray(dW))
         sharded.all_reduce_param_grads([dWt])
         ok[2] = bool(np.allclose(dWt.numpy(), dW_ref, rtol=2e-5, atol=1e-6))
-        tot = sharded.all_reduce_shard_losses(lt)
+        tot = sharded.all_reduce_shard_losses(lt, hi - lo, n, loss_weight=w)
         ok[3] = abs(float(tot) - float(loss_ref) * w) < 1e-5
         ret[rank] = tuple(ok)
     finally:
