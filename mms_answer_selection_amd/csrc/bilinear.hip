@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void gemm32_fast_kernel(GemmArgs g) {
 // backward a 5-8 us launch at the latency floor: U and V, then dQ, dA and dW, are independent of each
 // other).  Workgroup w of the 1-D grid belongs to the problem whose [first, first + count) holds w; operand
 // layouts are run-time flags.  No XCD remapping: the problems are small by construction.
-constexpr int kGroupMax = 3;
+constexpr int kGroupMax = 4;
 struct GemmGroup {
   GemmArgs g[kGroupMax];
   int first[kGroupMax + 1];      // first workgroup of each problem; first[n] = total
@@ -536,6 +536,7 @@ struct ReduceGroup {
   float* out[kGroupMax];
   long long n[kGroupMax];
   int splits[kGroupMax];
+  int accumulate[kGroupMax];     // the sum starts from out[e] (bias.diff += ..., sim_cross_layer.cpp:301-304) instead of 0
   int first[kGroupMax + 1];
   int cnt;
 };
@@ -549,8 +550,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroup rg
   const long long n = rg.n[p];
   const int splits = rg.splits[p];
   const long long stride = (long long)(rg.first[p + 1] - rg.first[p]) * 256;
+  const bool accumulate = rg.accumulate[p] != 0;
   for (long long e = (long long)(blockIdx.x - rg.first[p]) * 256 + threadIdx.x; e < n; e += stride) {
-    float s = 0.f;
+    float s = accumulate ? out[e] : 0.f;
     for (int k0 = 0; k0 < splits; k0 += 8) {     // same order and batching as splitk_reduce_kernel
       float v[8];
 #pragma unroll
@@ -738,6 +740,9 @@ struct BilinearWs {
   size_t u_off, v_off, part_off, mpart_off, mpart2_off, total;
   int ksplit, kchunk;
 };
+static bool pair_bwd_fits(int N, int W1, int W2, int D, int M) {      // = pair_bwd_eligible (defined with the kernel)
+  return W1 <= 48 && W2 <= 48 && D <= 64 && W1 * W2 > 1 && N <= 256 && (long long)N * M <= 65535;
+}
 static BilinearWs bilinear_ws(int N, int W1, int W2, int D, int M) {
   BilinearWs w{};
   const size_t u = (size_t)M * N * W1 * D, v = (size_t)M * N * W2 * D;
@@ -745,7 +750,9 @@ static BilinearWs bilinear_ws(int N, int W1, int W2, int D, int M) {
   w.u_off = 0;
   w.v_off = round_up(u * sizeof(float), 256);
   w.part_off = w.v_off + round_up(v * sizeof(float), 256);
-  w.mpart_off = w.part_off + round_up((size_t)w.ksplit * M * D * D * sizeof(float), 256);
+  // split-K slabs of dW -- or, when the fused per-pair backward runs, one D x D partial per (pair, measure)
+  const size_t slabs = pair_bwd_fits(N, W1, W2, D, M) && N > w.ksplit ? (size_t)N : (size_t)w.ksplit;
+  w.mpart_off = w.part_off + round_up(slabs * M * D * D * sizeof(float), 256);
   // per-measure partial products of dQ and of dA (M > 1 only): [M][N*W1][D], [M][N*W2][D]
   w.mpart2_off = w.mpart_off + (M > 1 ? round_up(u * sizeof(float), 256) : 0);
   w.total = w.mpart2_off + (M > 1 ? round_up(v * sizeof(float), 256) : 0);
@@ -907,6 +914,137 @@ __global__ __launch_bounds__(256) void bilinear_pair_fwd_kernel(
   }
 }
 
+
+// ---- fused backward for word grids at TRAINING batch sizes (the driver's 50 x 40 x 40 x Dw) -----------------
+// At a batch of 50 pairs every product of the bilinear backward is a 4-8 us launch at the latency floor (six
+// launches, 27 us).  Here ONE launch runs all five products of a (pair, measure): a workgroup stages q_n, a_n,
+// dT_nm and W_m as zero-padded LDS images (row stride 68, as in bilinear_pair_fwd_kernel), then
+//   phase 1   U = dT A (W1 x D), V = dT^T Q (W2 x D)              -> LDS
+//   phase 2   dQ_nm = U W_m^T, dA_nm = V W_m, dW_nm = Q^T U        -> per-(n, m) partials in the workspace
+// on v_mfma_f32_16x16x4_f32, the 16 x 16 output tiles of a phase dealt round-robin to the four waves.  The sums
+// the reference takes in place -- dQ_n over m (sim_cross_layer.cpp:291-294), dA_n over m (:296-299), dW_m over n
+// (:286-289) -- are taken afterwards by ONE grouped reduction launch in the same ascending orders.
+constexpr int FB_LS = 68, FB_W = 48, FB_D = 64;
+// KSW / KSD: k-steps of 4 over a word axis / the embedding axis, fixed at compile time so that a tile's operand
+// reads are ALL issued before its MFMAs (a rolled read-read-MFMA loop paid an LDS round trip per k-step: 17.6 us);
+// the images are zero beyond W and D, so steps past the real extent add exact zeros.
+template <int KSW, int KSD>
+__global__ __launch_bounds__(512) void bilinear_pair_bwd_kernel(
+    int N, int W1, int W2, int D, int M, const float* __restrict__ q, const float* __restrict__ a,
+    const float* __restrict__ W, const float* __restrict__ top_diff, float* __restrict__ mq,
+    float* __restrict__ ma, float* __restrict__ wpart) {
+  __shared__ float qs[FB_W * FB_LS], as[FB_W * FB_LS], ts[FB_W * FB_LS], ws[FB_D * FB_LS];
+  __shared__ float us[FB_W * FB_LS], vs[FB_W * FB_LS];
+  const int n = blockIdx.x / M, m = blockIdx.x - n * M;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, r = lane & 15, g = lane >> 4;
+  const float* qn = q + (size_t)n * W1 * D;
+  const float* an = a + (size_t)n * W2 * D;
+  const float* Wm = W + (size_t)m * D * D;
+  const float* dT = top_diff + ((size_t)n * M + m) * W1 * W2;
+  // zero-padded images: every load issued (clamped, unconditional) before the first LDS write
+  constexpr int NT = 512, NWV = NT / 64;
+  constexpr int NE = (FB_W * FB_LS + NT - 1) / NT, NEW = (FB_D * FB_LS + NT - 1) / NT;
+  {
+    float vq[NE], va[NE], vt[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = NT * u + t, row = e / FB_LS, c = e - row * FB_LS;
+      vq[u] = qn[(size_t)min(row, W1 - 1) * D + min(c, D - 1)];
+      va[u] = an[(size_t)min(row, W2 - 1) * D + min(c, D - 1)];
+      vt[u] = dT[(size_t)min(row, W1 - 1) * W2 + min(c, W2 - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = NT * u + t, row = e / FB_LS, c = e - row * FB_LS;
+      if (e < FB_W * FB_LS) {
+        qs[e] = (row < W1 && c < D) ? vq[u] : 0.f;
+        as[e] = (row < W2 && c < D) ? va[u] : 0.f;
+        ts[e] = (row < W1 && c < W2) ? vt[u] : 0.f;
+        us[e] = 0.f;                                   // rows / columns no tile writes must read as zero
+        vs[e] = 0.f;
+      }
+    }
+    float vw[NEW];
+#pragma unroll
+    for (int u = 0; u < NEW; ++u) {
+      const int e = NT * u + t, row = e / FB_LS, c = e - row * FB_LS;
+      vw[u] = Wm[(size_t)min(row, D - 1) * D + min(c, D - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < NEW; ++u) {
+      const int e = NT * u + t, row = e / FB_LS, c = e - row * FB_LS;
+      if (e < FB_D * FB_LS) ws[e] = (row < D && c < D) ? vw[u] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int tw1 = (W1 + 15) >> 4, tw2 = (W2 + 15) >> 4, td = (D + 15) >> 4;
+  // one 16 x 16 tile: C(i0 + 4g + j, j0 + r) = sum_k A(i0 + r', k) B(k, j0 + r); A / B given as (base, row stride,
+  // k stride): element (x, k) of an operand lives at base[x * xs + k * ks]
+  auto tile = [&](auto nks_tag, const float* A, int axs, int aks, const float* B, int bxs, int bks, int i0, int j0) {
+    constexpr int NKS = decltype(nks_tag)::value;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    const float* ap = A + (i0 + r) * axs + g * aks;
+    const float* bp = B + (j0 + r) * bxs + g * bks;
+    float av[NKS], bv[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) { av[ks] = ap[4 * ks * aks]; bv[ks] = bp[4 * ks * bks]; }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], acc, 0, 0, 0);
+    return acc;
+  };
+  const std::integral_constant<int, KSW> kw{};
+  const std::integral_constant<int, KSD> kd{};
+  auto put_lds = [&](float* dst, int i0, int j0, const v4f& acc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[(i0 + 4 * g + j) * FB_LS + j0 + r] = acc[j];
+  };
+  // phase 1: U (tw1 x td tiles) then V (tw2 x td tiles)
+  const int nU = tw1 * td, nV = tw2 * td;
+  for (int it = wave; it < nU + nV; it += NWV) {
+    if (it < nU) {
+      const int ti = it / td, tj = it - ti * td;
+      // U[j][d] = sum_k dT[j][k] A[k][d]:  A-operand (row j, k) = ts[j*LS + k];  B-operand (k, col d) = as[k*LS + d]
+      put_lds(us, 16 * ti, 16 * tj, tile(kw, ts, FB_LS, 1, as, 1, FB_LS, 16 * ti, 16 * tj));
+    } else {
+      const int e = it - nU, ti = e / td, tj = e - ti * td;
+      // V[k][d] = sum_j dT[j][k] Q[j][d]:  A-operand (row k, kk = j) = ts[j*LS + k];  B-operand (j, col d) = qs[j*LS + d]
+      put_lds(vs, 16 * ti, 16 * tj, tile(kw, ts, 1, FB_LS, qs, 1, FB_LS, 16 * ti, 16 * tj));
+    }
+  }
+  __syncthreads();
+  // phase 2
+  const int nQ = tw1 * td, nA = tw2 * td, nW = td * td;
+  float* mqn = mq + ((size_t)m * N + n) * W1 * D;       // [M][N*W1][D]
+  float* man = ma + ((size_t)m * N + n) * W2 * D;       // [M][N*W2][D]
+  float* wpn = wpart + ((size_t)n * M + m) * D * D;     // [N][M][D][D]
+  auto put_global = [&](float* dst, int ld, int rows, int cols, int i0, int j0, const v4f& acc) {
+    const int col = j0 + r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = i0 + 4 * g + j;
+      if (row < rows && col < cols) dst[(size_t)row * ld + col] = acc[j];
+    }
+  };
+  for (int it = wave; it < nQ + nA + nW; it += NWV) {
+    if (it < nQ) {
+      const int ti = it / td, tj = it - ti * td;
+      // dQ[j][d'] = sum_d U[j][d] W[d'][d]:  A (row j, k = d) = us[j*LS + d];  B (k = d, col d') = ws[d'*LS + d]
+      put_global(mqn, D, W1, D, 16 * ti, 16 * tj, tile(kd, us, FB_LS, 1, ws, FB_LS, 1, 16 * ti, 16 * tj));
+    } else if (it < nQ + nA) {
+      const int e = it - nQ, ti = e / td, tj = e - ti * td;
+      // dA[k][d'] = sum_d V[k][d] W[d][d']:  A (row k, kk = d) = vs[k*LS + d];  B (d, col d') = ws[d*LS + d']
+      put_global(man, D, W2, D, 16 * ti, 16 * tj, tile(kd, vs, FB_LS, 1, ws, 1, FB_LS, 16 * ti, 16 * tj));
+    } else {
+      const int e = it - nQ - nA, ti = e / td, tj = e - ti * td;
+      // dW[d][d'] = sum_j Q[j][d] U[j][d']:  A (row d, k = j) = qs[j*LS + d];  B (j, col d') = us[j*LS + d']
+      put_global(wpn, D, D, D, 16 * ti, 16 * tj, tile(kw, qs, 1, FB_LS, us, 1, FB_LS, 16 * ti, 16 * tj));
+    }
+  }
+}
+static bool pair_bwd_eligible(int N, int W1, int W2, int D, int M) {
+  return W1 <= FB_W && W2 <= FB_W && D <= FB_D && W1 * W2 > 1 && N <= 256 && (long long)N * M <= 65535;
+}
+
 int bilinear_forward(int N, int W1, int W2, int D, int M, const float* q, const float* a,
                      const float* W, const float* bias, float* top, void* ws, size_t ws_bytes,
                      hipStream_t s) {
@@ -961,6 +1099,36 @@ int bilinear_backward(int N, int W1, int W2, int D, int M, const float* q, const
   float* part = reinterpret_cast<float*>(base + lay.part_off);
   const long long R1 = (long long)N * W1, R2 = (long long)N * W2;
 
+  if (pair_bwd_eligible(N, W1, W2, D, M)) {
+    // one launch for the five products of every (pair, measure), one grouped launch for the three sums
+    float* mq = M > 1 ? reinterpret_cast<float*>(base + lay.mpart_off) : dq;
+    float* ma = M > 1 ? reinterpret_cast<float*>(base + lay.mpart2_off) : da;
+    if (W1 <= 40 && W2 <= 40 && D <= 52)           // the driver's geometry: 10 / 13 k-steps
+      hipLaunchKernelGGL((bilinear_pair_bwd_kernel<10, 13>), dim3(N * M), dim3(512), 0, s, N, W1, W2, D, M, q, a, W,
+                         top_diff, mq, ma, part);
+    else
+      hipLaunchKernelGGL((bilinear_pair_bwd_kernel<12, 16>), dim3(N * M), dim3(512), 0, s, N, W1, W2, D, M, q, a, W,
+                         top_diff, mq, ma, part);
+    ReduceGroup rg{};
+    const long long nWt = (long long)M * D * D;
+    int first = 0, cnt = 0;
+    auto add = [&](const float* p, float* o, long long n, int splits) {
+      rg.part[cnt] = p; rg.out[cnt] = o; rg.n[cnt] = n; rg.splits[cnt] = splits; rg.first[cnt] = first;
+      first += (int)ew_blocks(n);
+      ++cnt;
+    };
+    if (M > 1) { add(mq, dq, R1 * D, M); add(ma, da, R2 * D, M); }
+    add(part, dW, nWt, N);                           // W.diff is overwritten (:256), pairs summed ascending
+    if (bias_term) {
+      // bias.diff += dT_n, n ascending (:301-304): top_diff IS the [pair][M*W1*W2] stack of addends
+      add(top_diff, dbias, (long long)M * W1 * W2, N);
+      rg.accumulate[cnt - 1] = 1;
+    }
+    for (int i = cnt; i <= kGroupMax; ++i) rg.first[i] = first;
+    rg.cnt = cnt;
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(first), dim3(256), 0, s, rg);
+    return launch_status();
+  }
   // dbias first: it depends on nothing the products write
   if (bias_term) {
     const int per_n = M * W1 * W2;

@@ -1483,7 +1483,17 @@ static void launch_pair32w(const float* q, const float* a, const float* top_in, 
 template <bool FWD, bool BWD>
 static void launch_pair32(const float* q, const float* a, const float* top_in, const float* top_diff,
                           float* top_out, float* dq, float* da, int N, int D, hipStream_t s) {
-  launch_pair32w<FWD, BWD, 8>(q, a, top_in, top_diff, top_out, dq, da, N, D, s);
+  // dev switch for A/B timing (tools/layers_probe.py): MMS_PAIR32_WPB_FWD / _BWD / _FUSED = 2, 4, 8 or 16
+  static const int wpb = [] {
+    const char* e = std::getenv(FWD && BWD ? "MMS_PAIR32_WPB_FUSED" : FWD ? "MMS_PAIR32_WPB_FWD" : "MMS_PAIR32_WPB_BWD");
+    return e ? std::atoi(e) : 8;
+  }();
+  switch (wpb) {
+    case 2: launch_pair32w<FWD, BWD, 2>(q, a, top_in, top_diff, top_out, dq, da, N, D, s); break;
+    case 4: launch_pair32w<FWD, BWD, 4>(q, a, top_in, top_diff, top_out, dq, da, N, D, s); break;
+    case 16: launch_pair32w<FWD, BWD, 16>(q, a, top_in, top_diff, top_out, dq, da, N, D, s); break;
+    default: launch_pair32w<FWD, BWD, 8>(q, a, top_in, top_diff, top_out, dq, da, N, D, s); break;
+  }
 }
 
 template <bool FWD, bool BWD>
