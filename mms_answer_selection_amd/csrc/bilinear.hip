@@ -1041,6 +1041,90 @@ __global__ __launch_bounds__(512) void bilinear_pair_bwd_kernel(
     }
   }
 }
+
+// The forward twin of bilinear_pair_bwd_kernel for training batches: a workgroup per (pair, measure) stages q_n,
+// a_n and W_m, forms tmp = Q_n W_m in LDS and T_nm = tmp A_n^T (+ bias_m) straight to `top` -- one launch instead
+// of two batched GEMMs with a (M, N*W1, D) intermediate in HBM.  (bilinear_pair_fwd_kernel, one workgroup per
+// PAIR with W_m operands held in registers, stays the choice for evaluation batches of hundreds of pairs.)
+template <int KSD>
+__global__ __launch_bounds__(512) void bilinear_pairm_fwd_kernel(
+    int N, int W1, int W2, int D, int M, const float* __restrict__ q, const float* __restrict__ a,
+    const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ top) {
+  __shared__ float qs[FB_W * FB_LS], as[FB_W * FB_LS], ws[FB_D * FB_LS], ps[FB_W * FB_LS];
+  constexpr int NT = 512, NWV = NT / 64;
+  const int n = blockIdx.x / M, m = blockIdx.x - n * M;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, r = lane & 15, g = lane >> 4;
+  const float* qn = q + (size_t)n * W1 * D;
+  const float* an = a + (size_t)n * W2 * D;
+  const float* Wm = W + (size_t)m * D * D;
+  constexpr int NE = (FB_W * FB_LS + NT - 1) / NT, NEW = (FB_D * FB_LS + NT - 1) / NT;
+  {
+    float vq[NE], va[NE], vw[NEW];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = NT * u + t, row = e / FB_LS, c = e - row * FB_LS;
+      vq[u] = qn[(size_t)min(row, W1 - 1) * D + min(c, D - 1)];
+      va[u] = an[(size_t)min(row, W2 - 1) * D + min(c, D - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < NEW; ++u) {
+      const int e = NT * u + t, row = e / FB_LS, c = e - row * FB_LS;
+      vw[u] = Wm[(size_t)min(row, D - 1) * D + min(c, D - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = NT * u + t, row = e / FB_LS, c = e - row * FB_LS;
+      if (e < FB_W * FB_LS) {
+        qs[e] = (row < W1 && c < D) ? vq[u] : 0.f;
+        as[e] = (row < W2 && c < D) ? va[u] : 0.f;
+        ps[e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NEW; ++u) {
+      const int e = NT * u + t, row = e / FB_LS, c = e - row * FB_LS;
+      if (e < FB_D * FB_LS) ws[e] = (row < D && c < D) ? vw[u] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int tw1 = (W1 + 15) >> 4, tw2 = (W2 + 15) >> 4, td = (D + 15) >> 4;
+  auto tile = [&](const float* A, int axs, int aks, const float* B, int bxs, int bks, int i0, int j0) {
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    const float* ap = A + (i0 + r) * axs + g * aks;
+    const float* bp = B + (j0 + r) * bxs + g * bks;
+    float av[KSD], bv[KSD];
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) { av[ks] = ap[4 * ks * aks]; bv[ks] = bp[4 * ks * bks]; }
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], acc, 0, 0, 0);
+    return acc;
+  };
+  // tmp[j][d'] = sum_d Q[j][d] W[d][d']:  A (row j, k = d) = qs[j*LS + d];  B (d, col d') = ws[d*LS + d']
+  for (int it = wave; it < tw1 * td; it += NWV) {
+    const int ti = it / td, tj = it - ti * td;
+    const v4f acc = tile(qs, FB_LS, 1, ws, 1, FB_LS, 16 * ti, 16 * tj);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ps[(16 * ti + 4 * g + j) * FB_LS + 16 * tj + r] = acc[j];
+  }
+  __syncthreads();
+  // T[j][k] = sum_d' tmp[j][d'] A[k][d'] (+ bias[j][k]):  A (row j, k = d') = ps[j*LS + d'];  B (d', col k) = as[k*LS + d']
+  float* tn = top + ((size_t)n * M + m) * W1 * W2;
+  const float* bm = bias ? bias + (size_t)m * W1 * W2 : nullptr;
+  for (int it = wave; it < tw1 * tw2; it += NWV) {
+    const int ti = it / tw2, tj = it - ti * tw2;
+    const int col = 16 * tj + r;
+    float bvv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bvv[j] = bm ? bm[min(16 * ti + 4 * g + j, W1 - 1) * W2 + min(col, W2 - 1)] : 0.f;
+    const v4f acc = tile(ps, FB_LS, 1, as, FB_LS, 1, 16 * ti, 16 * tj);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 16 * ti + 4 * g + j;
+      if (row < W1 && col < W2) tn[row * W2 + col] = bm ? bvv[j] + acc[j] : acc[j];   // the addend form (:156-158)
+    }
+  }
+}
 static bool pair_bwd_eligible(int N, int W1, int W2, int D, int M) {
   return W1 <= FB_W && W2 <= FB_W && D <= FB_D && W1 * W2 > 1 && N <= 256 && (long long)N * M <= 65535;
 }
@@ -1059,6 +1143,13 @@ int bilinear_forward(int N, int W1, int W2, int D, int M, const float* q, const 
     else
       hipLaunchKernelGGL(bilinear_pair_fwd_kernel<16>, dim3(N), dim3(256), 0, s, N, W1, W2, D, M, q, a, W,
                          bias, top);
+    return launch_status();
+  }
+  if (pair_bwd_eligible(N, W1, W2, D, M)) {          // training batches: one launch, one workgroup per (pair, measure)
+    if (D <= 52)
+      hipLaunchKernelGGL((bilinear_pairm_fwd_kernel<13>), dim3(N * M), dim3(512), 0, s, N, W1, W2, D, M, q, a, W, bias, top);
+    else
+      hipLaunchKernelGGL((bilinear_pairm_fwd_kernel<16>), dim3(N * M), dim3(512), 0, s, N, W1, W2, D, M, q, a, W, bias, top);
     return launch_status();
   }
   float* tmp = reinterpret_cast<float*>(static_cast<char*>(ws) + lay.u_off);
