@@ -8,11 +8,11 @@
 # gpurun_out/prof_<ROUND>/summary/ (copy that into profiles/ to have it judged).
 # PMC passes use --kernel-trace only (no sys/hip/hsa tracing), as the pool requires.
 set -o pipefail
-R=${1:-r01}
+R=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT/summary
-ARGS="--steps 1024 --warmup 64 --no-cpu-baseline --no-variants"
+ARGS="--steps 1024 --warmup 64 --repeats 3 --no-cpu-baseline --no-variants $2"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $ROOT/bench.py $ARGS > $OUT/kt.out 2> $OUT/kt.err || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py $ARGS > $OUT/fetch.out 2> $OUT/fetch.err || exit 1

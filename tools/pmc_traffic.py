@@ -16,6 +16,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 
@@ -70,11 +71,32 @@ def main():
                       "FETCH_SIZE_KiB_per_launch_raw": f_kib, "WRITE_SIZE_KiB_per_launch_raw": w_kib,
                       "hbm_bytes_per_launch": hbm,
                       "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of 16B/lane streaming reads)"}
-        kn = k.replace("(bool)1", "true")
-        if ("euclid_pair32_kernel" in kn or "euclid_rows_wave_kernel" in kn) and "true, true" in kn:
-            traffic["fused"] = {"kernel": k, "hbm_bytes_per_launch": hbm}
+        kn = k.replace("(bool)1", "true").replace("(bool)0", "false")
+        # euclid_pair32_kernel<D4C, FWD, BWD, EXACT, WPB> / euclid_rows_wave_kernel<NIT, RW, FWD, BWD>
+        m = re.search(r"euclid_pair32_kernel<\s*\d+,\s*(true|false),\s*(true|false)", kn) or \
+            re.search(r"euclid_rows_wave_kernel<\s*\d+,\s*\d+,\s*(true|false),\s*(true|false)", kn)
+        if m:
+            fwd, bwd = m.group(1) == "true", m.group(2) == "true"
+            ent = {"kernel": k, "hbm_bytes_per_launch": hbm}
+            if fwd and bwd:
+                traffic["fused"] = ent
+            elif fwd:
+                traffic.setdefault("layers", {})["forward"] = ent
+            elif bwd:
+                traffic.setdefault("layers", {})["backward"] = ent
+    lay = traffic.get("layers")
+    if lay and "forward" in lay and "backward" in lay and lay["forward"]["hbm_bytes_per_launch"] and lay["backward"]["hbm_bytes_per_launch"]:
+        # one step of the Layer-API path = one Forward launch + one Backward launch
+        lay["hbm_bytes_per_step"] = lay["forward"]["hbm_bytes_per_launch"] + lay["backward"]["hbm_bytes_per_launch"]
     json.dump(summary, open(os.path.join(out, rnd + "_pmc.json"), "w"), indent=1)
     if traffic:
+        # keep entries of other paths collected in earlier runs (e.g. the fused variant)
+        old = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+        try:
+            for kk, vv in json.load(open(old)).items():
+                traffic.setdefault(kk, vv)
+        except Exception:
+            pass
         traffic["_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, round " + rnd
         json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
