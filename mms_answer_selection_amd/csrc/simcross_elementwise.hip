@@ -367,6 +367,146 @@ __global__ __launch_bounds__(64 * WPB) void euclid_pair32_kernel(
   MMS_STAMP(7);
 }
 
+// ---- the same algorithm with the global-memory side laid out by WORKGROUP, not by pair ----------
+// Measured (tools/launchbench.hip, profiles/r02_launchbench.txt): HBM-cold, a launch whose waves each read
+// two 512-byte pieces 1200 bytes apart per load instruction (the row-aligned layout above) takes 4.4 us for
+// q and a of cfg 2, a launch whose workgroup reads its rows as ONE dense run (instruction `it` of all its
+// waves covers a contiguous span) takes 3.6 us -- the speed of a flat one-float4-per-thread read; the
+// write side behaves the same (6.5 vs 5.5 us for a backward-shaped launch).  What costs is the order in
+// which a CU's requests reach a DRAM page: three visits at different times against one.
+// So: a workgroup of WPB waves owns R = 2*WPB consecutive pairs = C = R*D4C consecutive float4 of q and of
+// a; thread t loads float4s t, t+T, t+2T ... of that run (and stores dq / da the same way).  The squares
+// go to LDS at (pair, column) -- the image layout the chain wants -- and after ONE workgroup barrier each
+// half-wave walks its pair's chain exactly as in euclid_pair32_kernel (same predictions, same windows,
+// same bits).  A thread's float4s belong to whatever pairs they fall in, so the backward reads T (and the
+// per-pair coefficients) by pair index: from LDS when this launch computed T, from top_in otherwise -- a
+// backward-only launch has no LDS traffic and no barrier at all.
+template <int D4C, bool FWD, bool BWD, bool EXACT, int WPB>
+__global__ __launch_bounds__(64 * WPB) void euclid_block_kernel(
+    int N, const float* __restrict__ q, const float* __restrict__ a,
+    const float* __restrict__ top_in, const float* __restrict__ top_diff,
+    float* __restrict__ top_out, float* __restrict__ dq, float* __restrict__ da) {
+  constexpr int T = 64 * WPB, R = 2 * WPB, C = R * D4C;
+  constexpr int NIT = (C + T - 1) / T;                       // float4s per operand per thread
+  constexpr int PNIT = (D4C + 31) / 32, LASTN = D4C - 32 * (PNIT - 1);
+  constexpr int H4 = (D4C + 2) / 3, ST4 = 3 * H4;
+  __shared__ float4 lds4[FWD ? R * ST4 : 1];
+  __shared__ float Tl[(FWD && BWD) ? R : 1];
+  const int tid = threadIdx.x;
+  const long long total4 = (long long)N * D4C;
+  const long long b = (long long)blockIdx.x * C;
+  const float4* q4 = reinterpret_cast<const float4*>(q);
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+
+  float4 x[NIT], y[NIT], df[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = tid + T * it;
+    long long gi = b + ((NIT * T == C || i < C) ? i : 0);     // clamp: keep the load unconditional
+    gi = gi < total4 ? gi : total4 - 1;
+    x[it] = q4[gi];
+    y[it] = a4[gi];
+  }
+  // per-float4 pair coefficients of a backward-only launch: requested with the operands
+  float Tg[NIT], gg[NIT];
+  if (BWD) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + T * it;
+      long long row = (long long)blockIdx.x * R + ((NIT * T == C || i < C) ? i : 0) / D4C;
+      row = row < N ? row : N - 1;
+      gg[it] = top_diff[row];
+      if (!FWD) Tg[it] = top_in[row];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    df[it].x = x[it].x - y[it].x; df[it].y = x[it].y - y[it].y;
+    df[it].z = x[it].z - y[it].z; df[it].w = x[it].w - y[it].w;
+    if (FWD) {
+      const int i = tid + T * it;
+      float4 s;
+      s.x = df[it].x * df[it].x; s.y = df[it].y * df[it].y;
+      s.z = df[it].z * df[it].z; s.w = df[it].w * df[it].w;
+      if (NIT * T == C || i < C) lds4[(ST4 == D4C) ? i : (i / D4C) * ST4 + (i % D4C)] = s;
+    }
+  }
+  if (FWD) {
+    if (ST4 > D4C && tid < R * (ST4 - D4C))                 // zero tail of each image
+      lds4[(tid / (ST4 - D4C)) * ST4 + D4C + tid % (ST4 - D4C)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int grp = lane >> 5, j = lane & 31;
+    const int lp = wave * 2 + grp;
+    const long long row = (long long)blockIdx.x * R + lp;
+    const bool have = row < N;
+    const float4* img = lds4 + lp * ST4;
+    SpecSegment<H4> sg;
+    sg.load(img + spec_seg32(j) * H4);          // in flight while the window centres are formed
+    // tree-sum contributions to the two window centres (segment 0; segments 0-1): the same per-lane
+    // terms and the same reduction as euclid_pair32_kernel, read back from the image
+    const bool last_ok = (LASTN >= 32) || (j < LASTN);
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < PNIT; ++it) {
+      const bool valid = (it < PNIT - 1) || last_ok;
+      const float4 s = img[valid ? j + 32 * it : 0];
+      const float s4 = valid ? (s.x + s.y) + (s.z + s.w) : 0.f;
+      const int i = j + 32 * it;
+      if (32 * it + 31 < H4) p1 += s4;
+      else if (32 * it < H4) p1 += (i < H4) ? s4 : 0.f;
+      if (32 * it + 31 < 2 * H4) p2 += s4;
+      else if (32 * it < 2 * H4) p2 += (i < 2 * H4) ? s4 : 0.f;
+    }
+    p1 = half_wave_sum(p1);
+    p2 = half_wave_sum(p2);
+    __builtin_amdgcn_s_setprio(3);
+    const float2v start = spec_start32(p1, p2, j);
+    const float2v end = sg.chain(start);
+    bool hit;
+    float dist = spec_resolve_halves(start, end, j, &hit);
+    if (!hit) {                                 // uniform per half; exact re-walk of this lane's pair
+      MMS_COUNT_MISS();
+      dist = chain_sum_lds(img, ST4, 0.0f);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    const float Tp = 1.0f / (1.0f + sqrtf(dist));            // :106-107
+    if (j == 0) {
+      if (have) top_out[row] = Tp;
+      if (BWD) Tl[lp] = Tp;
+    }
+    if (BWD) __syncthreads();
+  }
+  if (!BWD) return;
+
+  float4* dq4 = reinterpret_cast<float4*>(dq);
+  float4* da4 = reinterpret_cast<float4*>(da);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = tid + T * it;
+    const bool live = (NIT * T == C || i < C) && (b + i < total4);
+    const float Tp = FWD ? Tl[((NIT * T == C || i < C) ? i : 0) / D4C] : Tg[it];
+    float4 t;
+    if (EXACT) {
+      const EuclidCoef k = euclid_coef(Tp, gg[it]);
+      t = euclid_tt4(k, df[it]);
+    } else {
+      const float c = gg[it] * Tp * Tp * Tp;
+      const float r = (float)rcp_newton((double)(Tp - 1.0f) + 1e-9);
+      t.x = (c * df[it].x) * r; t.y = (c * df[it].y) * r;
+      t.z = (c * df[it].z) * r; t.w = (c * df[it].w) * r;
+    }
+    if (live) {
+      // dq = 0 + tt ; da = 0 + (-tt)   (:176-177 zero, :219-220 accumulate once)
+      float4 o0, o1;
+      o0.x = 0.f + t.x; o0.y = 0.f + t.y; o0.z = 0.f + t.z; o0.w = 0.f + t.w;
+      o1.x = 0.f + (-t.x); o1.y = 0.f + (-t.y); o1.z = 0.f + (-t.z); o1.w = 0.f + (-t.w);
+      stream_store(dq4 + b + i, o0);
+      stream_store(da4 + b + i, o1);
+    }
+  }
+}
+
 // How the fp16-storage kernels sum a pair's squares (include/mms.h: mms_set_f16_distance_mode); per calling thread.
 static thread_local int t_f16_distance_mode = MMS_F16_DISTANCE_ORDERED;
 int f16_distance_mode() { return t_f16_distance_mode; }
@@ -1465,14 +1605,38 @@ static void launch_pair32w(const float* q, const float* a, const float* top_in, 
                            float* top_out, float* dq, float* da, int N, int D, hipStream_t s) {
   const unsigned grid = (unsigned)((N + 2 * WPB - 1) / (2 * WPB));
   const bool exact = BWD && euclid_backward_mode() == MMS_EUCLID_BWD_REFERENCE;
+  // Which global-memory layout (same results bit for bit; tests/test_gpu_parity.py runs both for every kind
+  // of launch).  Measured at cfg 2, HBM-cold, graph-replayed (tools/layoutab.sh, profiles/r02_layout_ab.txt):
+  //   backward-only launch      row-aligned 6.27 us, workgroup-dense 4.87 us  -> dense
+  //   forward-only launch       4.87 vs 4.92 us: the chain's tail, not the read pattern, bounds it -> row-aligned
+  //   fused forward+backward    5.65 vs 6.0 us: waves free of workgroup barriers spread the store phase -> row-aligned
+  //   Forward launch then Backward launch (what a Net issues): 8.80 us both row-aligned -> 7.97 us forward
+  //   row-aligned + backward dense.  Both must map workgroup b to the SAME pairs (same waves per workgroup):
+  //   the backward then finds q and a in the L2 of the XCD that read them in the forward; mismatched maps cost
+  //   0.6 us.
+  // Dev switch for A/B timing: MMS_EUCLID_LAYOUT_{FWD,BWD,FUSED} = pair | block.
+  static const bool pair_layout = [] {
+    const char* e = std::getenv(FWD && BWD ? "MMS_EUCLID_LAYOUT_FUSED" : FWD ? "MMS_EUCLID_LAYOUT_FWD" : "MMS_EUCLID_LAYOUT_BWD");
+    if (e) return !std::strcmp(e, "pair");
+    return FWD;
+  }();
 #define MMS_P32(d4)                                                                                  \
   case 4 * d4:                                                                                       \
-    if (exact)                                                                                       \
-      hipLaunchKernelGGL((euclid_pair32_kernel<d4, FWD, BWD, true, WPB>), dim3(grid), dim3(64 * WPB), \
-                         0, s, N, q, a, top_in, top_diff, top_out, dq, da);                          \
-    else                                                                                             \
-      hipLaunchKernelGGL((euclid_pair32_kernel<d4, FWD, BWD, false, WPB>), dim3(grid),               \
-                         dim3(64 * WPB), 0, s, N, q, a, top_in, top_diff, top_out, dq, da);          \
+    if (pair_layout) {                                                                               \
+      if (exact)                                                                                     \
+        hipLaunchKernelGGL((euclid_pair32_kernel<d4, FWD, BWD, true, WPB>), dim3(grid),              \
+                           dim3(64 * WPB), 0, s, N, q, a, top_in, top_diff, top_out, dq, da);        \
+      else                                                                                           \
+        hipLaunchKernelGGL((euclid_pair32_kernel<d4, FWD, BWD, false, WPB>), dim3(grid),             \
+                           dim3(64 * WPB), 0, s, N, q, a, top_in, top_diff, top_out, dq, da);        \
+    } else {                                                                                         \
+      if (exact)                                                                                     \
+        hipLaunchKernelGGL((euclid_block_kernel<d4, FWD, BWD, true, WPB>), dim3(grid),               \
+                           dim3(64 * WPB), 0, s, N, q, a, top_in, top_diff, top_out, dq, da);        \
+      else                                                                                           \
+        hipLaunchKernelGGL((euclid_block_kernel<d4, FWD, BWD, false, WPB>), dim3(grid),              \
+                           dim3(64 * WPB), 0, s, N, q, a, top_in, top_diff, top_out, dq, da);        \
+    }                                                                                                \
     break;
   switch (D) { MMS_P32(25) MMS_P32(50) MMS_P32(75) }
 #undef MMS_P32
