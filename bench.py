@@ -363,7 +363,7 @@ def run(args):
         step_us = t_ms * 1e3 / K
         achieved = B_UNFUSED / (step_us * 1e-6) / 1e9 if args.path != "triplet" else None
         kernel = {"fused": "mms::euclid_pair32_kernel<75,true,true,...> (SimCross Euclid fwd+bwd, one launch)",
-                  "layers": "mms::euclid_pair32_kernel<75,true,false,...> (Forward) then <75,false,true,...> (Backward)",
+                  "layers": "mms::euclid_pair32_kernel<75,true,false,...> (Forward launch) then mms::euclid_block_kernel<75,false,true,...> (Backward launch)",
                   "triplet": "mms::triplet32_kernel<75,...> + loss_finish_kernel"}[args.path]
         mode = capi.get_euclid_backward_mode()
         out = {
@@ -433,7 +433,15 @@ def run(args):
 
     # side measurements on rank 0 at N=1 only (not part of the timed region above)
     if rank == 0 and world == 1 and not args.no_variants:
-        out["roofline"].update(per_kernel_roofline(torch, capi)) if "roofline" in out else None
+        if "roofline" in out:
+            out["roofline"].update(per_kernel_roofline(torch, capi))
+            fl = out["roofline"]["launch_floor"]["us_per_empty_launch"] * launches_per_step
+            above = max(out["roofline"]["avg_step_us_hip_events"] - fl, 1e-3)
+            out["roofline"]["launch_floor"].update({
+                "launches_per_step": launches_per_step, "us_per_step": fl,
+                "step_us_above_launch_floor": above,
+                "GBps_above_launch_floor": B_UNFUSED / (above * 1e-6) / 1e9,
+                "frac_ceiling_if_data_were_free": B_UNFUSED / (fl * 1e-6) / 1e9 / HBM_PEAK_GBS})
         out["variants"] = variants(torch, capi, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
@@ -482,7 +490,29 @@ def per_kernel_roofline(torch, capi):
         res[name] = {"us_per_launch": us, "algorithmic_bytes": nbytes,
                      "achieved_GBps": nbytes / (us * 1e-6) / 1e9,
                      "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
-    return {"per_kernel_cold": res}
+    # what a launch costs by itself under the same protocol: 256 empty kernels (256 x 512 threads) per region
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph, stream=cap):
+            for i in range(32):
+                capi.null_launch(256)
+    torch.cuda.current_stream().wait_stream(cap)
+    ts = []
+    for rep in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for r in range(8):
+            gph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / 256)
+    floor = median(ts)
+    return {"per_kernel_cold": res,
+            "launch_floor": {"us_per_empty_launch": floor,
+                             "note": "an EMPTY kernel (mms_null_launch, 256 x 512 threads) replayed under the same "
+                                     "hipGraph protocol: a step of L launches cannot take less than L x this"}}
 
 
 def run_cfg5(args, torch, dist, capi, world, rank):

@@ -77,6 +77,12 @@ int mms_get_euclid_backward_mode(void);
  *   MMS_PAIRRANK_HINGE_GPU:           `ordered >= 0`, the PairRankLossBackward kernel that Backward_gpu
  *                                     launches (src/caffe/layers/pair_rank_loss_layer.cu:51).
  * Set per calling thread, like the Euclidean mode above. */
+/* Measurement aid (no reference counterpart): launches an EMPTY kernel of `workgroups` x 512 threads on
+ * `stream`.  bench.py replays it under the same hipGraph protocol as the Layer-API sequence to report what a
+ * launch costs by itself on this box (about 2.0 us per graph kernel node on MI355X), i.e. how much of a
+ * two-launch step no kernel can remove. */
+int mms_null_launch(int workgroups, void* stream);
+
 /* out[0] = sum_i x[i]*y[i], all three on the device (one workgroup, fixed summation tree).  The Layer mirror's
  * Forward uses it for loss tops in GPU mode where the reference calls caffe_gpu_dot
  * (include/caffe/layer.hpp:469-481, src/caffe/util/math_functions.cu caffe_gpu_dot). */

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "mms_pairrank_backward_f64": (_i, [_i, C.c_double] + [_vp] * 3 + [_i, _i] + [_vp] * 3),
     "mms_set_euclid_backward_mode": (_i, [_i]),
     "mms_get_euclid_backward_mode": (_i, []),
+    "mms_null_launch": (_i, [_i, _vp]),
     "mms_dot_f32": (_i, [_i, _vp, _vp, _vp, _vp]),
     "mms_dot_f64": (_i, [_i, _vp, _vp, _vp, _vp]),
     "mms_set_f16_distance_mode": (_i, [_i]),
@@ -337,6 +338,11 @@ def feed_gather_rows(src, first, rows, dst, perm=None):
                                          _ptr(perm, "perm", True, dtype=torch.int32), first,
                                          _ptr(dst, "dst"), _stream()),
           "mms_feed_gather_rows_f32")
+
+
+def null_launch(workgroups=256):
+    """An empty kernel of `workgroups` x 512 threads on the current stream (measurement aid: the launch floor)."""
+    check(lib().mms_null_launch(int(workgroups), _stream()), "mms_null_launch")
 
 
 EUCLID_BWD_FP32, EUCLID_BWD_REFERENCE = 0, 1

@@ -111,6 +111,9 @@ hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 // x . y with the result left on the device (fixed-shape tree: deterministic); what Layer::Forward needs for a
 // loss top in GPU mode (include/caffe/layer.hpp:469-481 calls caffe_gpu_dot there)
 namespace mms {
+// measurement aid (include/mms.h: mms_null_launch)
+__global__ __launch_bounds__(512) void null_kernel(int) {}
+
 template <typename T>
 __global__ __launch_bounds__(256) void dot_kernel(int n, const T* __restrict__ x, const T* __restrict__ y,
                                                   T* __restrict__ out) {
@@ -402,6 +405,11 @@ int mms_set_euclid_backward_mode(int mode) {
 }
 int mms_get_euclid_backward_mode(void) { return euclid_backward_mode(); }
 
+int mms_null_launch(int workgroups, void* stream) {
+  if (workgroups <= 0) return MMS_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(mms::null_kernel, dim3(workgroups), dim3(512), 0, as_stream(stream), workgroups);
+  return launch_status();
+}
 int mms_dot_f32(int n, const float* x, const float* y, float* out, void* stream) {
   if (n < 0 || !out || (n > 0 && (!x || !y))) return MMS_ERR_INVALID_ARG;
   hipLaunchKernelGGL(mms::dot_kernel<float>, dim3(1), dim3(256), 0, as_stream(stream), n, x, y, out);

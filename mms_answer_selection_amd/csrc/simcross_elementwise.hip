@@ -381,20 +381,29 @@ __global__ __launch_bounds__(64 * WPB) void euclid_pair32_kernel(
 // same bits).  A thread's float4s belong to whatever pairs they fall in, so the backward reads T (and the
 // per-pair coefficients) by pair index: from LDS when this launch computed T, from top_in otherwise -- a
 // backward-only launch has no LDS traffic and no barrier at all.
-template <int D4C, bool FWD, bool BWD, bool EXACT, int WPB>
+// SPAN = waves that share one dense run: WPB (the whole workgroup, one barrier) or 1 (each wave reads its own two
+// rows as a dense run and synchronises with nobody: the chain phases of a CU's waves then start as their own data
+// arrives instead of all at once).
+template <int D4C, bool FWD, bool BWD, bool EXACT, int WPB, int SPAN = WPB>
 __global__ __launch_bounds__(64 * WPB) void euclid_block_kernel(
     int N, const float* __restrict__ q, const float* __restrict__ a,
     const float* __restrict__ top_in, const float* __restrict__ top_diff,
     float* __restrict__ top_out, float* __restrict__ dq, float* __restrict__ da) {
-  constexpr int T = 64 * WPB, R = 2 * WPB, C = R * D4C;
+  static_assert(SPAN == WPB || SPAN == 1, "a dense run belongs to the workgroup or to one wave");
+  constexpr int T = 64 * SPAN, R = 2 * SPAN, C = R * D4C;
+  constexpr int NSPAN = WPB / SPAN;                          // runs per workgroup
   constexpr int NIT = (C + T - 1) / T;                       // float4s per operand per thread
   constexpr int PNIT = (D4C + 31) / 32, LASTN = D4C - 32 * (PNIT - 1);
   constexpr int H4 = (D4C + 2) / 3, ST4 = 3 * H4;
-  __shared__ float4 lds4[FWD ? R * ST4 : 1];
-  __shared__ float Tl[(FWD && BWD) ? R : 1];
-  const int tid = threadIdx.x;
+  __shared__ float4 lds4_all[FWD ? NSPAN * R * ST4 : 1];
+  __shared__ float Tl_all[(FWD && BWD) ? NSPAN * R : 1];
+  const int span = (SPAN == WPB) ? 0 : (int)(threadIdx.x >> 6);
+  const int tid = (SPAN == WPB) ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+  float4* lds4 = lds4_all + (FWD ? span * R * ST4 : 0);
+  float* Tl = Tl_all + ((FWD && BWD) ? span * R : 0);
+  const long long run = (long long)blockIdx.x * NSPAN + span;   // index of this dense run
   const long long total4 = (long long)N * D4C;
-  const long long b = (long long)blockIdx.x * C;
+  const long long b = run * C;
   const float4* q4 = reinterpret_cast<const float4*>(q);
   const float4* a4 = reinterpret_cast<const float4*>(a);
 
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(64 * WPB) void euclid_block_kernel(
   for (int it = 0; it < NIT; ++it) {
     const int i = tid + T * it;
     long long gi = b + ((NIT * T == C || i < C) ? i : 0);     // clamp: keep the load unconditional
-    gi = gi < total4 ? gi : total4 - 1;
+    gi = gi < total4 ? gi : total4 - 1;                       // a run past the end reads the last float4
     x[it] = q4[gi];
     y[it] = a4[gi];
   }
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(64 * WPB) void euclid_block_kernel(
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = tid + T * it;
-      long long row = (long long)blockIdx.x * R + ((NIT * T == C || i < C) ? i : 0) / D4C;
+      long long row = run * R + ((NIT * T == C || i < C) ? i : 0) / D4C;
       row = row < N ? row : N - 1;
       gg[it] = top_diff[row];
       if (!FWD) Tg[it] = top_in[row];
@@ -434,11 +443,11 @@ __global__ __launch_bounds__(64 * WPB) void euclid_block_kernel(
   if (FWD) {
     if (ST4 > D4C && tid < R * (ST4 - D4C))                 // zero tail of each image
       lds4[(tid / (ST4 - D4C)) * ST4 + D4C + tid % (ST4 - D4C)] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
+    if (SPAN == WPB) __syncthreads(); else wave_lds_sync();
     const int wave = tid >> 6, lane = tid & 63;
     const int grp = lane >> 5, j = lane & 31;
     const int lp = wave * 2 + grp;
-    const long long row = (long long)blockIdx.x * R + lp;
+    const long long row = run * R + lp;
     const bool have = row < N;
     const float4* img = lds4 + lp * ST4;
     SpecSegment<H4> sg;
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(64 * WPB) void euclid_block_kernel(
       if (have) top_out[row] = Tp;
       if (BWD) Tl[lp] = Tp;
     }
-    if (BWD) __syncthreads();
+    if (BWD) { if (SPAN == WPB) __syncthreads(); else wave_lds_sync(); }
   }
   if (!BWD) return;
 
@@ -1504,6 +1513,133 @@ static size_t cross_bwd_tiled_lds(int mode, int W1, int W2) {
   return tables + (size_t)(W1 + W2) * (kBwdDC + 1) * sizeof(float) + 16;
 }
 
+// ---- Euclidean cross-geometry backward for MANY pairs of narrow word grids (cfg 4's 1517 x 40 x 40 x 50) ------
+// cross_bwd_tiled_kernel computes every term tt[j,k,d] twice (once in the k-ordered sum of dq[j,d], once in
+// the j-ordered sum of da[k,d]) and wastes 44 % of its second 32-wide d chunk at D = 50.  Here ONE WAVE owns a
+// pair and a LANE owns a column d: the lane walks j (outer) and k (inner) over all W1*W2 terms of its column,
+// each computed ONCE; dq[j,d] is the running sum over k inside one j (k ascending, as :209-223), and the W2
+// accumulators da[k,d] stay in registers across the j loop (j ascending) -- the reference's accumulation
+// orders, so the Euclidean results keep their bits.  The per-(j,k) coefficients are wave-uniform: built once
+// into LDS (c and fl32(1/den), or c, den, 1/den for the reference rounding) and read back as broadcasts.
+// W2 is a compile-time constant (even; the widths the dispatcher instantiates -- the reference pads sentences to
+// one length, 40 in network_v4): the k loop is straight-line code, two k per packed sub / mul / mul, with all
+// of a row's coefficient reads in flight together.  Other widths keep cross_bwd_tiled_kernel.
+template <int W2C, bool EXACT>
+__global__ __launch_bounds__(64) void cross_bwd_lane_kernel(
+    const float* __restrict__ q, const float* __restrict__ a, const float* __restrict__ top,
+    const float* __restrict__ top_diff, float* __restrict__ dq, float* __restrict__ da, int W1, int D) {
+  static_assert(W2C % 2 == 0, "two k per packed operation");
+  constexpr int KP = W2C / 2;
+  extern __shared__ __attribute__((aligned(16))) double lds_lane[];
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int JK = W1 * W2C;
+  // tables (index e = j*W2C + k, the blob's own order): EXACT: double den[], double rcp[], float c[];
+  // otherwise float2 (c, fl32(1/den))[]
+  double* t_den = lds_lane;
+  double* t_rcp = lds_lane + (EXACT ? JK : 0);
+  float* t_c = reinterpret_cast<float*>(lds_lane + (EXACT ? 2 * JK : 0));
+  // fp32 mode: W2C/2 float4 (c_k, c_k+1, r_k, r_k+1) per row j
+  const float* Tn = top + (size_t)n * JK;
+  const float* gn = top_diff + (size_t)n * JK;
+  for (int e0 = lane; e0 < JK; e0 += 64 * 8) {
+    float tv[8], gv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int e = min(e0 + 64 * u, JK - 1); tv[u] = Tn[e]; gv[u] = gn[e]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 64 * u;
+      if (e >= JK) break;
+      const EuclidCoef kc = euclid_coef(tv[u], gv[u]);
+      if (EXACT) { t_c[e] = kc.c; t_den[e] = kc.den; t_rcp[e] = kc.rcp; }
+      else {                                             // per k pair: (c_k, c_k+1, r_k, r_k+1)
+        float* f = reinterpret_cast<float*>(lds_lane);
+        const int p4 = (e >> 1) * 4 + (e & 1);           // W2C even: pairs never straddle rows
+        f[p4] = kc.c;
+        f[p4 + 2] = (float)kc.rcp;
+      }
+    }
+  }
+  const bool live = lane < D;
+  const int d = live ? lane : D - 1;
+  const float* qn = q + (size_t)n * W1 * D + d;
+  const float* an = a + (size_t)n * W2C * D + d;
+  float2v av[KP], acc[KP];
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp) {
+    av[kp].x = an[(size_t)(2 * kp) * D];
+    av[kp].y = an[(size_t)(2 * kp + 1) * D];
+    acc[kp] = (float2v){0.f, 0.f};
+  }
+  wave_lds_sync();
+  float* dqn = dq + (size_t)n * W1 * D + d;
+  if (EXACT) {
+    float qv = qn[0];
+    for (int j = 0; j < W1; ++j) {
+      const float qnext = qn[(size_t)min(j + 1, W1 - 1) * D];
+      float accq = 0.f;
+#pragma unroll
+      for (int kp = 0; kp < KP; ++kp) {
+        EuclidCoef k0, k1;
+        const int e = j * W2C + 2 * kp;
+        k0.c = t_c[e]; k0.den = t_den[e]; k0.rcp = t_rcp[e];
+        k1.c = t_c[e + 1]; k1.den = t_den[e + 1]; k1.rcp = t_rcp[e + 1];
+        float2v tt;
+        tt.x = euclid_tt(k0, qv - av[kp].x);
+        tt.y = euclid_tt(k1, qv - av[kp].y);
+        accq += tt.x;
+        accq += tt.y;
+        acc[kp] = acc[kp] - tt;                            // da += -tt, j ascending
+      }
+      if (live) dqn[(size_t)j * D] = accq;
+      qv = qnext;
+    }
+  } else {
+    typedef float float4v __attribute__((ext_vector_type(4)));
+    const float4v* tab = reinterpret_cast<const float4v*>(lds_lane);
+    // a row's W2C/2 (c0, c1, r0, r1) entries are read together at the top of its iteration (16-byte broadcast
+    // reads); the next q value is requested one iteration ahead.  Measured alternatives at 1517 x 40 x 40 x 50
+    // (this form: 39.5 us; cross_bwd_tiled_kernel: 62): a second row buffer (ping-pong) needs 290 VGPRs = one
+    // wave per SIMD, 61 us; re-loading each entry right after its use 44 us; q staged through LDS as well 42.5 us.
+    // What bounds it is the LDS return path -- every wave reads its whole 12.8 KB table for all 64 lanes, 18 us
+    // of LDS cycles per CU -- next to the VALU issue of the SIMDs that hold two of the 1517 waves.
+    float qv = qn[0];
+    for (int j = 0; j < W1; ++j) {
+      const float qnext = qn[(size_t)min(j + 1, W1 - 1) * D];
+      const float2v qq = {qv, qv};
+      float4v cr[KP];
+#pragma unroll
+      for (int kp = 0; kp < KP; ++kp) cr[kp] = tab[(size_t)j * KP + kp];
+      float accq = 0.f;
+#pragma unroll
+      for (int kp = 0; kp < KP; ++kp) {
+        const float2v c = {cr[kp].x, cr[kp].y}, r = {cr[kp].z, cr[kp].w};
+        const float2v tt = (c * (qq - av[kp])) * r;
+        accq += tt.x;
+        accq += tt.y;
+        acc[kp] = acc[kp] - tt;                            // da += -tt, j ascending
+      }
+      if (live) dqn[(size_t)j * D] = accq;
+      qv = qnext;
+    }
+  }
+  float* dan = da + (size_t)n * W2C * D + d;
+  if (live) {
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+      dan[(size_t)(2 * kp) * D] = acc[kp].x;
+      dan[(size_t)(2 * kp + 1) * D] = acc[kp].y;
+    }
+  }
+}
+static size_t cross_bwd_lane_lds(bool exact, int W1, int W2) {
+  return (size_t)W1 * W2 * (exact ? 8 + 8 + 4 : 8) + 16;
+}
+// the lane kernel pays when there are enough pairs to give every SIMD a wave and the grids are narrow
+static bool cross_bwd_lane_ok(bool exact, int N, int W1, int W2, int D) {
+  const bool width = W2 == 8 || W2 == 16 || W2 == 20 || W2 == 24 || W2 == 32 || W2 == 40 || W2 == 48;
+  return !exact && width && D <= 64 && N >= 512 && cross_bwd_lane_lds(exact, W1, W2) <= 64 * 1024;
+}
+
 // ================================ dispatch ==================================
 
 template <int MODE>
@@ -1614,32 +1750,35 @@ static void launch_pair32w(const float* q, const float* a, const float* top_in, 
   //   row-aligned + backward dense.  Both must map workgroup b to the SAME pairs (same waves per workgroup):
   //   the backward then finds q and a in the L2 of the XCD that read them in the forward; mismatched maps cost
   //   0.6 us.
-  // Dev switch for A/B timing: MMS_EUCLID_LAYOUT_{FWD,BWD,FUSED} = pair | block.
-  static const bool pair_layout = [] {
+  // Dev switch for A/B timing: MMS_EUCLID_LAYOUT_{FWD,BWD,FUSED} = pair | block | wave (dense run per wave).
+  static const int layout = [] {
     const char* e = std::getenv(FWD && BWD ? "MMS_EUCLID_LAYOUT_FUSED" : FWD ? "MMS_EUCLID_LAYOUT_FWD" : "MMS_EUCLID_LAYOUT_BWD");
-    if (e) return !std::strcmp(e, "pair");
-    return FWD;
+    if (e) return !std::strcmp(e, "pair") ? 0 : (!std::strcmp(e, "wave") ? 2 : 1);
+    return FWD ? 0 : 1;
   }();
+#define MMS_P32_GO(K, ...)                                                                          \
+  do {                                                                                               \
+    if (exact)                                                                                       \
+      hipLaunchKernelGGL((K<__VA_ARGS__, FWD, BWD, true, WPB>), dim3(grid), dim3(64 * WPB), 0, s, N, \
+                         q, a, top_in, top_diff, top_out, dq, da);                                   \
+    else                                                                                             \
+      hipLaunchKernelGGL((K<__VA_ARGS__, FWD, BWD, false, WPB>), dim3(grid), dim3(64 * WPB), 0, s,   \
+                         N, q, a, top_in, top_diff, top_out, dq, da);                                \
+  } while (0)
 #define MMS_P32(d4)                                                                                  \
   case 4 * d4:                                                                                       \
-    if (pair_layout) {                                                                               \
-      if (exact)                                                                                     \
-        hipLaunchKernelGGL((euclid_pair32_kernel<d4, FWD, BWD, true, WPB>), dim3(grid),              \
-                           dim3(64 * WPB), 0, s, N, q, a, top_in, top_diff, top_out, dq, da);        \
-      else                                                                                           \
-        hipLaunchKernelGGL((euclid_pair32_kernel<d4, FWD, BWD, false, WPB>), dim3(grid),             \
-                           dim3(64 * WPB), 0, s, N, q, a, top_in, top_diff, top_out, dq, da);        \
-    } else {                                                                                         \
-      if (exact)                                                                                     \
-        hipLaunchKernelGGL((euclid_block_kernel<d4, FWD, BWD, true, WPB>), dim3(grid),               \
-                           dim3(64 * WPB), 0, s, N, q, a, top_in, top_diff, top_out, dq, da);        \
-      else                                                                                           \
-        hipLaunchKernelGGL((euclid_block_kernel<d4, FWD, BWD, false, WPB>), dim3(grid),              \
-                           dim3(64 * WPB), 0, s, N, q, a, top_in, top_diff, top_out, dq, da);        \
-    }                                                                                                \
+    if (layout == 0) MMS_P32_GO(euclid_pair32_kernel, d4);                                           \
+    else if (layout == 1) MMS_P32_GO(euclid_block_kernel, d4);                                       \
+    else if (exact)                                                                                  \
+      hipLaunchKernelGGL((euclid_block_kernel<d4, FWD, BWD, true, WPB, 1>), dim3(grid),              \
+                         dim3(64 * WPB), 0, s, N, q, a, top_in, top_diff, top_out, dq, da);          \
+    else                                                                                             \
+      hipLaunchKernelGGL((euclid_block_kernel<d4, FWD, BWD, false, WPB, 1>), dim3(grid),             \
+                         dim3(64 * WPB), 0, s, N, q, a, top_in, top_diff, top_out, dq, da);          \
     break;
   switch (D) { MMS_P32(25) MMS_P32(50) MMS_P32(75) }
 #undef MMS_P32
+#undef MMS_P32_GO
 }
 
 // Eight waves (16 pairs) per workgroup: N = 4096 is then 256 workgroups, one per CU, two waves
@@ -1771,6 +1910,20 @@ int simcross_elementwise_backward(int mode, int N, int W1, int W2, int D,
       hipLaunchKernelGGL((cosine_rows_kernel<false, false, true>), dim3(grid), dim3(256), 0, s, q, a,
                          top_diff, const_cast<float*>(top), const_cast<float*>(norm0),
                          const_cast<float*>(norm1), dq, da, N, D);
+  } else if (mode == 1 && cross_bwd_lane_ok(euclid_backward_mode() == MMS_EUCLID_BWD_REFERENCE, N, W1, W2, D)) {
+    const bool exact = euclid_backward_mode() == MMS_EUCLID_BWD_REFERENCE;
+    const size_t lds = cross_bwd_lane_lds(exact, W1, W2);
+#define MMS_LANE(W2_)                                                                                     \
+  case W2_:                                                                                               \
+    if (exact)                                                                                            \
+      hipLaunchKernelGGL((cross_bwd_lane_kernel<W2_, true>), dim3((unsigned)N), dim3(64), lds, s, q, a,   \
+                         top, top_diff, dq, da, W1, D);                                                   \
+    else                                                                                                  \
+      hipLaunchKernelGGL((cross_bwd_lane_kernel<W2_, false>), dim3((unsigned)N), dim3(64), lds, s, q, a,  \
+                         top, top_diff, dq, da, W1, D);                                                   \
+    break;
+    switch (W2) { MMS_LANE(8) MMS_LANE(16) MMS_LANE(20) MMS_LANE(24) MMS_LANE(32) MMS_LANE(40) MMS_LANE(48) }
+#undef MMS_LANE
   } else if (cross_bwd_tiled_lds(mode, W1, W2) <= 64 * 1024 &&
              2LL * N * ((D + kBwdDC - 1) / kBwdDC) <= 0x7fffffffLL) {
     const int nchunks = (D + kBwdDC - 1) / kBwdDC;

@@ -12,8 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_non_default_layouts_are_bitexact(hiplib, oracle):
-    env = dict(os.environ, MMS_EUCLID_LAYOUT_FWD="block", MMS_EUCLID_LAYOUT_BWD="pair", MMS_EUCLID_LAYOUT_FUSED="block")
+@pytest.mark.parametrize("fwd,bwd,fused", [("block", "pair", "block"), ("wave", "wave", "wave"), ("pair", "block", "pair")])
+def test_every_layout_is_bitexact(fwd, bwd, fused, hiplib, oracle):
+    env = dict(os.environ, MMS_EUCLID_LAYOUT_FWD=fwd, MMS_EUCLID_LAYOUT_BWD=bwd, MMS_EUCLID_LAYOUT_FUSED=fused)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "layout_gpu_worker.py")],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]

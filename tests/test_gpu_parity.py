@@ -49,6 +49,10 @@ EUCLID_SHAPES = [
     (3, 1, 1, 1028),     # beyond the wave kernel: generic rows kernel
     (1, 70, 60, 9),      # W1*W2 tables exceed LDS: generic cross backward
     (2, 1, 1, 2100),     # rows wider than every rows kernel: cross kernels with W = 1
+    (600, 40, 40, 50),   # many narrow word grids: lane-per-column backward (cross_bwd_lane_kernel), W2 even
+    (513, 7, 8, 33),     # ... narrowest instantiated width
+    (520, 47, 48, 64),   # ... its largest geometry
+    (515, 5, 24, 10),
 ]
 
 

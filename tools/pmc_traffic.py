@@ -72,8 +72,8 @@ def main():
                       "hbm_bytes_per_launch": hbm,
                       "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of 16B/lane streaming reads)"}
         kn = k.replace("(bool)1", "true").replace("(bool)0", "false")
-        # euclid_pair32_kernel<D4C, FWD, BWD, EXACT, WPB> / euclid_rows_wave_kernel<NIT, RW, FWD, BWD>
-        m = re.search(r"euclid_pair32_kernel<\s*\d+,\s*(true|false),\s*(true|false)", kn) or \
+        # euclid_pair32_kernel / euclid_block_kernel<D4C, FWD, BWD, EXACT, WPB> / euclid_rows_wave_kernel<NIT, RW, FWD, BWD>
+        m = re.search(r"euclid_(?:pair32|block)_kernel<\s*\d+,\s*(true|false),\s*(true|false)", kn) or \
             re.search(r"euclid_rows_wave_kernel<\s*\d+,\s*\d+,\s*(true|false),\s*(true|false)", kn)
         if m:
             fwd, bwd = m.group(1) == "true", m.group(2) == "true"
