@@ -885,7 +885,22 @@ def other_configs(torch, capi):
     out["cfg4_scoring_from_word_ids_1517x40x40x50"] = {
         "us_per_step_embed_then_simcross": us2, "us_per_step_fused": us1, "pairs_per_s": n / (us1 * 1e-6),
         "note": "Embed gather fused into SimCross's loads (mms_embed_simcross_forward_f32) vs three launches"}
-    del tab, iq, ia, qe, ae, tg
+    # ... and in the mode network_v4 scores with (bilinear, M = 4, bias)
+    Wb = torch.rand(4, 50, 50, device="cuda", generator=g) * 0.16 - 0.08
+    bb = torch.zeros(4, 40, 40, device="cuda")
+    tb = torch.empty(n, 4, 40, 40, device="cuda")
+
+    def embed_then_bilinear():
+        capi.embed_forward(iq, tab, qe.view(-1, 50))
+        capi.embed_forward(ia, tab, ae.view(-1, 50))
+        capi.simcross_forward(2, qe, ae, tb, W=Wb, bias=bb, ws=ws)
+    us2 = _graph_time(torch, embed_then_bilinear)
+    us1 = _graph_time(torch, lambda: capi.embed_simcross_bilinear_forward(iq, ia, tab, Wb, bb, tb))
+    out["cfg4_scoring_bilinear_M4_from_word_ids_1517x40x40x50"] = {
+        "us_per_step_embed_then_simcross": us2, "us_per_step_fused": us1, "pairs_per_s": n / (us1 * 1e-6),
+        "note": "mms_embed_simcross_bilinear_forward_f32: the word-grid forward gathers its q / a images from the "
+                "table itself, one launch"}
+    del tab, iq, ia, qe, ae, tg, Wb, bb, tb
     n = 1517
     sc = torch.rand(n, device="cuda", generator=g)
     prob = torch.stack([1 - sc, sc], 1).contiguous()

@@ -27,6 +27,7 @@ _SIGNATURES = {
     "mms_simcross_forward_backward_f32": (_i, [_i] * 6 + [_vp] * 13 + [_sz, _vp]),
     "mms_simmatrix_workspace_bytes": (_sz, [_i] * 3),
     "mms_embed_simcross_forward_f32": (_i, [_i] * 6 + [_vp] * 7),
+    "mms_embed_simcross_bilinear_forward_f32": (_i, [_i] * 6 + [_vp] * 7),
     "mms_simmatrix_forward_f32": (_i, [_i] * 3 + [_vp] * 6),
     "mms_simmatrix_backward_f32": (_i, [_i] * 3 + [_vp] * 4 + [_i] * 3 + [_vp] * 4 + [_sz, _vp]),
     "mms_simmatrix_backward_cached_f32": (_i, [_i] * 3 + [_vp] * 5 + [_i] * 3 + [_vp] * 4 + [_sz, _vp]),
@@ -190,6 +191,18 @@ def embed_simcross_forward(mode, index_q, index_a, weight, top, norm0=None, norm
         mode, N, W1, W2, D, K, _ptr(index_q, "index_q"), _ptr(index_a, "index_a"), _ptr(weight, "weight"),
         _ptr(top, "top"), _ptr(norm0, "norm0", True), _ptr(norm1, "norm1", True), _stream()),
         "mms_embed_simcross_forward_f32")
+
+
+def embed_simcross_bilinear_forward(index_q, index_a, weight, W, bias, top):
+    """top (N,M,W1,W2) = SimCross dist_mode 2 of (Embed(index_q), Embed(index_a)), one launch (word grids)."""
+    N, W1 = index_q.shape[0], index_q.shape[1]
+    W2 = index_a.shape[1]
+    K, D = weight.shape
+    M = W.shape[0]
+    check(lib().mms_embed_simcross_bilinear_forward_f32(
+        N, W1, W2, D, M, K, _ptr(index_q, "index_q"), _ptr(index_a, "index_a"), _ptr(weight, "weight"),
+        _ptr(W, "W"), _ptr(bias, "bias", True), _ptr(top, "top"), _stream()),
+        "mms_embed_simcross_bilinear_forward_f32")
 
 
 def simmatrix_forward(q, a, W, top, qw_scratch):

@@ -785,10 +785,24 @@ __device__ __forceinline__ void wave_lds_sync_local() {
 constexpr int PF_LS = 68, PF_ROWS = 48, PF_TD = 4;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Embed fused into the staging loads (the mode network_v4 scores with): with g.iq != nullptr,
+// q and a are both the embedding TABLE (K x D) and row r of pair n is table row g.iq[n*W1 + r] (g.ia likewise):
+// the (N, W, D) blobs the Embed layers would write and SimCross read back never exist.
+struct PairGather {
+  const float* iq;
+  const float* ia;
+  int K;
+};
+__device__ __forceinline__ int pair_gather_id(float v, int K) {   // as mms_embed_forward_f32 clamps
+  const int i = (int)v;
+  return i < 0 ? 0 : (i >= K ? K - 1 : i);
+}
+
 template <int KS>                                  // k steps of 4: 13 covers D <= 52 (the driver's 50), 16 D <= 64
 __global__ __launch_bounds__(256) void bilinear_pair_fwd_kernel(
     int N, int W1, int W2, int D, int M, const float* __restrict__ q, const float* __restrict__ a,
-    const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ top) {
+    const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ top,
+    PairGather g = PairGather{nullptr, nullptr, 0}) {
   __shared__ float qs[PF_ROWS * PF_LS];
   __shared__ float as[PF_ROWS * PF_LS];
   __shared__ float ts[4][16 * PF_LS];
@@ -827,12 +841,29 @@ __global__ __launch_bounds__(256) void bilinear_pair_fwd_kernel(
   // zero-padded images: every load issued (clamped, unconditional) before the first LDS write
   constexpr int NE = (PF_ROWS * PF_LS + 255) / 256;
   float vq[NE], va[NE];
+  if (g.iq) {                                      // ids first (all in flight), then the table rows
+    float fq[NE], fa[NE];
 #pragma unroll
-  for (int u = 0; u < NE; ++u) {
-    const int e = 256 * u + t;
-    const int r = e / PF_LS, c = e - r * PF_LS;
-    vq[u] = qn[(size_t)min(r, W1 - 1) * D + min(c, D - 1)];
-    va[u] = an[(size_t)min(r, W2 - 1) * D + min(c, D - 1)];
+    for (int u = 0; u < NE; ++u) {
+      const int r = (256 * u + t) / PF_LS;
+      fq[u] = g.iq[(size_t)n * W1 + min(r, W1 - 1)];
+      fa[u] = g.ia[(size_t)n * W2 + min(r, W2 - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = 256 * u + t;
+      const int c = e - (e / PF_LS) * PF_LS;
+      vq[u] = q[(size_t)pair_gather_id(fq[u], g.K) * D + min(c, D - 1)];
+      va[u] = a[(size_t)pair_gather_id(fa[u], g.K) * D + min(c, D - 1)];
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = 256 * u + t;
+      const int r = e / PF_LS, c = e - r * PF_LS;
+      vq[u] = qn[(size_t)min(r, W1 - 1) * D + min(c, D - 1)];
+      va[u] = an[(size_t)min(r, W2 - 1) * D + min(c, D - 1)];
+    }
   }
 #pragma unroll
   for (int u = 0; u < NE; ++u) {
@@ -1049,7 +1080,8 @@ __global__ __launch_bounds__(512) void bilinear_pair_bwd_kernel(
 template <int KSD>
 __global__ __launch_bounds__(512) void bilinear_pairm_fwd_kernel(
     int N, int W1, int W2, int D, int M, const float* __restrict__ q, const float* __restrict__ a,
-    const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ top) {
+    const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ top,
+    PairGather gth = PairGather{nullptr, nullptr, 0}) {
   __shared__ float qs[FB_W * FB_LS], as[FB_W * FB_LS], ws[FB_D * FB_LS], ps[FB_W * FB_LS];
   constexpr int NT = 512, NWV = NT / 64;
   const int n = blockIdx.x / M, m = blockIdx.x - n * M;
@@ -1060,11 +1092,27 @@ __global__ __launch_bounds__(512) void bilinear_pairm_fwd_kernel(
   constexpr int NE = (FB_W * FB_LS + NT - 1) / NT, NEW = (FB_D * FB_LS + NT - 1) / NT;
   {
     float vq[NE], va[NE], vw[NEW];
+    if (gth.iq) {                                  // Embed fused in: ids first, then the table rows
+      float fq[NE], fa[NE];
 #pragma unroll
-    for (int u = 0; u < NE; ++u) {
-      const int e = NT * u + t, row = e / FB_LS, c = e - row * FB_LS;
-      vq[u] = qn[(size_t)min(row, W1 - 1) * D + min(c, D - 1)];
-      va[u] = an[(size_t)min(row, W2 - 1) * D + min(c, D - 1)];
+      for (int u = 0; u < NE; ++u) {
+        const int row = (NT * u + t) / FB_LS;
+        fq[u] = gth.iq[(size_t)n * W1 + min(row, W1 - 1)];
+        fa[u] = gth.ia[(size_t)n * W2 + min(row, W2 - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < NE; ++u) {
+        const int e = NT * u + t, c = e - (e / FB_LS) * FB_LS;
+        vq[u] = q[(size_t)pair_gather_id(fq[u], gth.K) * D + min(c, D - 1)];
+        va[u] = a[(size_t)pair_gather_id(fa[u], gth.K) * D + min(c, D - 1)];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NE; ++u) {
+        const int e = NT * u + t, row = e / FB_LS, c = e - row * FB_LS;
+        vq[u] = qn[(size_t)min(row, W1 - 1) * D + min(c, D - 1)];
+        va[u] = an[(size_t)min(row, W2 - 1) * D + min(c, D - 1)];
+      }
     }
 #pragma unroll
     for (int u = 0; u < NEW; ++u) {
@@ -1127,6 +1175,34 @@ __global__ __launch_bounds__(512) void bilinear_pairm_fwd_kernel(
 }
 static bool pair_bwd_eligible(int N, int W1, int W2, int D, int M) {
   return W1 <= FB_W && W2 <= FB_W && D <= FB_D && W1 * W2 > 1 && N <= 256 && (long long)N * M <= 65535;
+}
+
+// top = SimCross_bilinear(Embed(index_q), Embed(index_a)) in ONE launch, for the word-grid geometries the two
+// fused forward kernels cover (W1, W2 <= 48, D <= 64): embed_layer.cpp:135-152 (bias_term false) followed by
+// sim_cross_layer.cpp:140-161, the gather done by the staging loads.  Same kernels, same operand values: the
+// bits of mms_embed_forward_f32 x2 followed by mms_simcross_forward_f32.  Other geometries: MMS_ERR_UNSUPPORTED.
+int embed_bilinear_forward(int N, int W1, int W2, int D, int M, int K, const float* index_q,
+                           const float* index_a, const float* table, const float* W, const float* bias,
+                           float* top, hipStream_t s) {
+  if (N == 0) return MMS_OK;
+  const PairGather g{index_q, index_a, K};
+  if (W1 <= PF_ROWS && W2 <= PF_ROWS && D <= 16 * PF_TD && W1 * W2 > 1 && N >= 512) {
+    if (D <= 52)
+      hipLaunchKernelGGL(bilinear_pair_fwd_kernel<13>, dim3(N), dim3(256), 0, s, N, W1, W2, D, M, table, table, W,
+                         bias, top, g);
+    else
+      hipLaunchKernelGGL(bilinear_pair_fwd_kernel<16>, dim3(N), dim3(256), 0, s, N, W1, W2, D, M, table, table, W,
+                         bias, top, g);
+    return launch_status();
+  }
+  if (pair_bwd_eligible(N, W1, W2, D, M)) {
+    if (D <= 52)
+      hipLaunchKernelGGL((bilinear_pairm_fwd_kernel<13>), dim3(N * M), dim3(512), 0, s, N, W1, W2, D, M, table, table, W, bias, top, g);
+    else
+      hipLaunchKernelGGL((bilinear_pairm_fwd_kernel<16>), dim3(N * M), dim3(512), 0, s, N, W1, W2, D, M, table, table, W, bias, top, g);
+    return launch_status();
+  }
+  return MMS_ERR_UNSUPPORTED;
 }
 
 int bilinear_forward(int N, int W1, int W2, int D, int M, const float* q, const float* a,

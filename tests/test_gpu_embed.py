@@ -81,6 +81,47 @@ def test_embed_fused_into_simcross_forward(cfg, oracle, hiplib):
     assert_bitexact(t1.cpu().numpy(), t2.cpu().numpy(), "clamped ids")
 
 
+@pytest.mark.parametrize("cfg", [(1517, 40, 40, 50, 4, 20000, True), (600, 16, 24, 64, 2, 300, False),
+                                 (50, 40, 40, 50, 4, 1000, True), (7, 9, 13, 33, 3, 40, True)])
+def test_embed_fused_into_bilinear_forward(cfg, oracle, hiplib):
+    """mms_embed_simcross_bilinear_forward_f32 (dist_mode 2, the mode network_v4 scores with) == Embed x2 followed
+    by SimCross: the same kernels on the same operand values, so the same BITS as the three separate calls; 1e-5
+    against the oracle (BLAS order in the reference).  Covers both fused forward kernels (evaluation batches of
+    >= 512 pairs, training batches of <= 256)."""
+    from mms_answer_selection_amd import capi
+    N, W1, W2, D, M, K, use_bias = cfg
+    r = rng(sum(cfg[:6]))
+    weight = r.uniform(-0.5, 0.5, (K, D)).astype(np.float32)
+    iq = r.integers(0, K, (N, W1)).astype(np.float32)
+    ia = r.integers(0, K, (N, W2)).astype(np.float32)
+    ia[r.uniform(size=ia.shape) < 0.4] = K - 1          # zero-pad id
+    iq[0, 0] = -2.0                                      # clamped like mms_embed_forward_f32
+    ia[-1, -1] = K + 7.0
+    Wm = (r.standard_normal((M, D, D)) * 0.1).astype(np.float32)
+    bias = r.standard_normal((M, W1, W2)).astype(np.float32) if use_bias else None
+    q = oracle.embed_forward(np.clip(iq, 0, K - 1).reshape(-1), weight, None).reshape(N, W1, D)
+    a = oracle.embed_forward(np.clip(ia, 0, K - 1).reshape(-1), weight, None).reshape(N, W2, D)
+    top_ref, _, _ = oracle.simcross_forward(2, q, a, W=Wm, bias=bias)
+    top = torch.full(top_ref.shape, float("nan"), device="cuda")
+    wd, Wd, bd = dev(weight), dev(Wm), (dev(bias) if use_bias else None)
+    capi.embed_simcross_bilinear_forward(dev(iq), dev(ia), wd, Wd, bd, top)
+    assert_close(top.cpu().numpy(), top_ref, TOL, "bilinear scores of the fused call")
+    qd = torch.empty(N, W1, D, device="cuda"); ad = torch.empty(N, W2, D, device="cuda")
+    capi.embed_forward(dev(iq).view(-1), wd, qd.view(N * W1, D))
+    capi.embed_forward(dev(ia).view(-1), wd, ad.view(N * W2, D))
+    top2 = torch.full(top_ref.shape, float("nan"), device="cuda")
+    capi.simcross_forward(2, qd, ad, top2, W=Wd, bias=bd)
+    assert_bitexact(top.cpu().numpy(), top2.cpu().numpy(), "fused == Embed, Embed, SimCross")
+
+
+def test_embed_fused_bilinear_refuses_other_geometries(hiplib):
+    from mms_answer_selection_amd import capi
+    N, W1, W2, D, M, K = 3, 40, 40, 300, 2, 50                # D beyond the fused forward kernels
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    with pytest.raises(capi.MMSError):
+        capi.embed_simcross_bilinear_forward(z(N, W1), z(N, W2), z(K, D), z(M, D, D), None, z(N, M, W1, W2))
+
+
 def test_embed_layer_weight_sources_and_chain(tmp_path, oracle, hiplib):
     from mms_answer_selection_amd import layers as L
     L.lib(); L.set_mode_gpu()
