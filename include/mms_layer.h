@@ -111,8 +111,11 @@ int mms_layer_run_f64(const char* prototxt, int nbottom, const int* bottom_axes,
                       double* const* param_diff_out, char* err, int err_len);
 
 /* ------------------------------------------------------------------------- *
- * .caffemodel snapshots (binary NetParameter).  Host-only
- * except the two *_layer functions, which touch Blob memory.
+ * Snapshots.  mms_snapshot_open reads a binary NetParameter (.caffemodel: the current
+ * `layer` list, and the V1 `layers` / V0 lists of older files with their enum types mapped to type strings as
+ * Caffe's upgrade does) or an HDF5-format snapshot (snapshot_format: HDF5, /data/<layer>/<index>; recognised
+ * by its signature; such files carry no layer types).  Host-only except the two *_layer functions, which touch
+ * Blob memory.
  * ------------------------------------------------------------------------- */
 typedef struct mms_snapshot mms_snapshot_t;
 typedef struct mms_snapshot_writer mms_snapshot_writer_t;
@@ -138,6 +141,8 @@ void mms_snapshot_writer_add_blob(mms_snapshot_writer_t* w, const int* shape, in
 /* Layer::ToProto (include/caffe/layer.hpp:506-514). */
 void mms_snapshot_writer_add_from_layer(mms_snapshot_writer_t* w, mms_layer_t* layer, const char* name);
 int mms_snapshot_writer_save(const mms_snapshot_writer_t* w, const char* path);
+/* Net::ToHDF5 (net.cpp:893-960), data only; at most 8 parameter layers per file. */
+int mms_snapshot_writer_save_hdf5(const mms_snapshot_writer_t* w, const char* path, char* err, int err_len);
 
 /* ------------------------------------------------------------------------- *
  * HDF5 batch files, host only.  What the "HDF5Data" layer uses

@@ -16,8 +16,15 @@
 //   BlobProto      { shape = 7 (BlobShape), data = 5 (packed float), diff = 6,
 //                    double_data = 8 (packed double), num/channels/height/width = 1..4 }
 //   BlobShape      { dim = 1 (packed int64) }
-// Unknown fields are skipped, as a protobuf parser does.  The V1 `layers = 2` list
-// of pre-2015 snapshots is not read (the fork's layers never existed in V1).
+//   V1LayerParameter (NetParameter.layers = 2, pre-2015 snapshots; caffe.proto:1286-1345)
+//                  { name = 4, type = 5 (enum -> the type string UpgradeV1LayerType gives it,
+//                    util/upgrade_proto.cpp:865-950), blobs = 6, layer = 1 (V0LayerParameter:
+//                    name = 1, type = 2, blobs = 50) }
+// Unknown fields are skipped, as a protobuf parser does.  Both lists are read -- Caffe upgrades
+// V0/V1 snapshots to `layer` before matching names (Net::CopyTrainedLayersFrom sees only names and blobs).
+// HDF5-format snapshots (snapshot_format: HDF5; Net::ToHDF5 / CopyTrainedLayersFromHDF5, net.cpp:797-844,
+// 893-960: /data/<layer name>/<param index>, float datasets) go through csrc/hdf5_io.cpp; a file is taken for
+// HDF5 by its signature, whatever its name (the reference looks at the ".h5" suffix, net.cpp:778-785).
 // tests/test_snapshot.py cross-checks both directions against google.protobuf.
 #include <cstdint>
 #include <cstdio>
@@ -26,7 +33,11 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "caffe_api.hpp"
+#include "hdf5_io.hpp"
 #include "mms_layer.h"
 
 namespace {
@@ -143,6 +154,71 @@ bool parse_layer(Reader r, SnapLayer* l) {
   return r.ok;
 }
 
+// V1LayerParameter.LayerType -> LayerParameter.type (the table of util/upgrade_proto.cpp:865-950, as data)
+const char* v1_type_name(int t) {
+  static const struct { int v; const char* n; } kTab[] = {
+      {35, "AbsVal"}, {1, "Accuracy"}, {30, "ArgMax"}, {2, "BNLL"}, {3, "Concat"}, {37, "ContrastiveLoss"},
+      {4, "Convolution"}, {39, "Deconvolution"}, {5, "Data"}, {6, "Dropout"}, {32, "DummyData"},
+      {7, "EuclideanLoss"}, {25, "Eltwise"}, {38, "Exp"}, {8, "Flatten"}, {9, "HDF5Data"}, {10, "HDF5Output"},
+      {28, "HingeLoss"}, {11, "Im2col"}, {12, "ImageData"}, {13, "InfogainLoss"}, {14, "InnerProduct"},
+      {15, "LRN"}, {29, "MemoryData"}, {16, "MultinomialLogisticLoss"}, {34, "MVN"}, {17, "Pooling"},
+      {26, "Power"}, {18, "ReLU"}, {19, "Sigmoid"}, {27, "SigmoidCrossEntropyLoss"}, {36, "Silence"},
+      {20, "Softmax"}, {21, "SoftmaxWithLoss"}, {22, "Split"}, {33, "Slice"}, {23, "TanH"}, {24, "WindowData"},
+      {31, "Threshold"}};
+  for (const auto& e : kTab)
+    if (e.v == t) return e.n;
+  return "";
+}
+
+// V0LayerParameter (nested in a V1 layer as `layer = 1`): name = 1, type = 2 (string), blobs = 50
+bool parse_v0_layer(Reader r, SnapLayer* l) {
+  while (r.ok && !r.done()) {
+    const uint64_t key = r.varint();
+    const int field = (int)(key >> 3), wt = (int)(key & 7);
+    if ((field == 1 || field == 2) && wt == 2) {
+      Reader s = r.sub();
+      (field == 1 ? l->name : l->type).assign((const char*)s.p, (size_t)(s.end - s.p));
+    } else if (field == 50 && wt == 2) {
+      SnapBlob b;
+      if (!parse_blob(r.sub(), &b)) return false;
+      l->blobs.push_back(std::move(b));
+    } else {
+      r.skip(wt);
+    }
+  }
+  return r.ok;
+}
+
+bool parse_v1_layer(Reader r, SnapLayer* l) {
+  SnapLayer v0;
+  bool has_v0 = false;
+  while (r.ok && !r.done()) {
+    const uint64_t key = r.varint();
+    const int field = (int)(key >> 3), wt = (int)(key & 7);
+    if (field == 4 && wt == 2) {
+      Reader s = r.sub();
+      l->name.assign((const char*)s.p, (size_t)(s.end - s.p));
+    } else if (field == 5 && wt == 0) {
+      l->type = v1_type_name((int)r.varint());
+    } else if (field == 6 && wt == 2) {
+      SnapBlob b;
+      if (!parse_blob(r.sub(), &b)) return false;
+      l->blobs.push_back(std::move(b));
+    } else if (field == 1 && wt == 2) {
+      if (!parse_v0_layer(r.sub(), &v0)) return false;
+      has_v0 = true;
+    } else {
+      r.skip(wt);
+    }
+  }
+  if (has_v0) {                                     // a V0 net wrapped in V1 connections: the V0 message has it all
+    if (l->name.empty()) l->name = v0.name;
+    if (l->type.empty()) l->type = v0.type;
+    if (l->blobs.empty()) l->blobs = std::move(v0.blobs);
+  }
+  return r.ok;
+}
+
 // ------------------------------- wire-format writer --------------------------
 void put_varint(std::string* o, uint64_t v) {
   while (v >= 0x80) { o->push_back((char)(v | 0x80)); v >>= 7; }
@@ -176,7 +252,40 @@ std::string encode_layer(const SnapLayer& l) {
 struct mms_snapshot {
   std::string net_name;
   std::vector<SnapLayer> layers;
+  bool hdf5 = false;
 };
+
+namespace {
+// /data/<layer name>/<param index> -> SnapLayer{name, "", blobs in index order}; HDF5 snapshots carry no types
+mms_snapshot* open_hdf5_snapshot(const char* path, std::string* err) {
+  mms_h5::File f;
+  if (!f.Open(path, err)) return nullptr;
+  std::unique_ptr<mms_snapshot> s(new mms_snapshot);
+  s->hdf5 = true;
+  bool has_data = false;
+  for (const std::string& g : f.GroupNames()) {
+    if (g == "data") has_data = true;
+    if (g.compare(0, 5, "data/") == 0 && g.find('/', 5) == std::string::npos) {
+      SnapLayer l;
+      l.name = g.substr(5);
+      s->layers.push_back(std::move(l));
+    }
+  }
+  if (!has_data) { *err = std::string("Error reading weights from ") + path + ": no /data group"; return nullptr; }
+  for (SnapLayer& l : s->layers) {
+    for (int j = 0;; ++j) {
+      const std::string ds = "data/" + l.name + "/" + std::to_string(j);
+      if (!f.Find(ds)) break;
+      SnapBlob b;
+      mms_h5::DatasetInfo info;
+      if (!f.ReadFloat(ds, &info, &b.data, err)) return nullptr;
+      for (int64_t d : info.dims) b.shape.push_back((int)d);
+      l.blobs.push_back(std::move(b));
+    }
+  }
+  return s.release();
+}
+}  // namespace
 
 extern "C" {
 
@@ -192,6 +301,16 @@ mms_snapshot_t* mms_snapshot_open(const char* path, char* err, int err_len) {
   size_t n;
   while ((n = std::fread(chunk, 1, sizeof(chunk), f)) > 0) buf.append(chunk, n);
   std::fclose(f);
+  static const unsigned char kH5[8] = {0x89, 'H', 'D', 'F', 0x0d, 0x0a, 0x1a, 0x0a};
+  bool is_h5 = false;
+  for (size_t off = 0; off + 8 <= buf.size(); off = off ? off * 2 : 512)   // the signature may follow a user block
+    if (!std::memcmp(buf.data() + off, kH5, 8)) { is_h5 = true; break; }
+  if (is_h5) {
+    std::string e;
+    mms_snapshot* hs = open_hdf5_snapshot(path, &e);
+    if (!hs && err && err_len > 0) std::snprintf(err, err_len, "%s", e.c_str());
+    return hs;
+  }
   std::unique_ptr<mms_snapshot> s(new mms_snapshot);
   Reader r{(const uint8_t*)buf.data(), (const uint8_t*)buf.data() + buf.size()};
   while (r.ok && !r.done()) {
@@ -203,6 +322,10 @@ mms_snapshot_t* mms_snapshot_open(const char* path, char* err, int err_len) {
     } else if (field == 100 && wt == 2) {
       SnapLayer l;
       if (!parse_layer(r.sub(), &l)) return fail("malformed LayerParameter in");
+      s->layers.push_back(std::move(l));
+    } else if (field == 2 && wt == 2) {              // V1 `layers`
+      SnapLayer l;
+      if (!parse_v1_layer(r.sub(), &l)) return fail("malformed V1LayerParameter in");
       s->layers.push_back(std::move(l));
     } else {
       r.skip(wt);
@@ -287,6 +410,28 @@ void mms_snapshot_writer_add_from_layer(mms_snapshot_writer_t* w, mms_layer_t* l
     for (int ax = 0; ax < mms_blob_num_axes(b); ++ax) shape.push_back(mms_blob_shape(b, ax));
     mms_snapshot_writer_add_blob(w, shape.data(), (int)shape.size(), mms_blob_cpu(b, 0));
   }
+}
+// Net::ToHDF5 (net.cpp:893-960), data only: /data/<layer name>/<param index>, float32, the blob's shape.
+// Layers without parameters get no group (the reference writes an empty one; nothing reads it).  The in-tree
+// HDF5 writer holds at most 8 members per group: 8 parameter layers per file.
+int mms_snapshot_writer_save_hdf5(const mms_snapshot_writer_t* w, const char* path, char* err, int err_len) {
+  std::vector<mms_h5::WriteDataset> sets;
+  for (const SnapLayer& l : w->layers) {
+    for (size_t j = 0; j < l.blobs.size(); ++j) {
+      mms_h5::WriteDataset d;
+      d.name = "data/" + l.name + "/" + std::to_string(j);
+      for (int x : l.blobs[j].shape) d.dims.push_back(x);
+      d.elem_size = 4;
+      d.values.assign(l.blobs[j].data.begin(), l.blobs[j].data.end());
+      sets.push_back(std::move(d));
+    }
+  }
+  std::string e;
+  if (!mms_h5::WriteContiguous(path, sets, &e)) {
+    if (err && err_len > 0) std::snprintf(err, err_len, "%s", e.c_str());
+    return 1;
+  }
+  return 0;
 }
 int mms_snapshot_writer_save(const mms_snapshot_writer_t* w, const char* path) {
   std::string out;

@@ -97,8 +97,37 @@ bool File::Open(const std::string& path, std::string* err) {
   return WalkGroupTree(base_ + btree, heap_data, 0, err);
 }
 
-// III.A.1 version-1 B-tree, node type 0 (group nodes); leaves point at SNODs (III.B).
-bool File::WalkGroupTree(uint64_t node, uint64_t heap_data, int depth, std::string* err) {
+// Is the object at `hdr` a (symbol-table) group?  Fills btree / heap-data addresses.  A link's cache type 1
+// carries them in its scratch space; otherwise the object header's symbol-table message (0x11) does.
+bool File::GroupOf(uint64_t entry, uint64_t* btree, uint64_t* heap_data) const {
+  uint64_t bt = kUndef, hp = kUndef;
+  if ((uint32_t)U(entry + 16, 4) == 1) {
+    bt = U(entry + 24, 8);
+    hp = U(entry + 32, 8);
+  } else {
+    const uint64_t a = base_ + U(entry + 8, 8);
+    if (!In(a, 16) || buf_[a] != 1) return false;
+    const int nmsg = (int)U(a + 2, 2);
+    uint64_t q = a + 16;
+    const uint64_t end = q + U(a + 8, 4);
+    for (int i = 0; i < nmsg && q + 8 <= end && In(q, 8); ++i) {
+      const int type = (int)U(q, 2), size = (int)U(q + 2, 2);
+      if (type == 0x11 && In(q + 8, 16)) { bt = U(q + 8, 8); hp = U(q + 16, 8); }
+      q += 8 + size;
+    }
+  }
+  if (bt == kUndef || hp == kUndef) return false;
+  const uint64_t h = base_ + hp;
+  if (!In(h, 32) || std::memcmp(buf_.data() + h, "HEAP", 4)) return false;
+  *btree = base_ + bt;
+  *heap_data = base_ + U(h + 24, 8);
+  return true;
+}
+
+// III.A.1 version-1 B-tree, node type 0 (group nodes); leaves point at SNODs (III.B).  Members that are
+// groups themselves are walked too and their datasets recorded under "group/member" paths (the layout of the
+// reference's HDF5 snapshots: /data/<layer name>/<param index>, net.cpp:797-844).
+bool File::WalkGroupTree(uint64_t node, uint64_t heap_data, int depth, std::string* err, const std::string& prefix) {
   if (depth > kMaxDepth || ++nodes_visited_ > kMaxNodes) return fail(err, "group B-tree too deep or cyclic");
   if (!In(node, 24)) return fail(err, "group node outside the file");
   if (!std::memcmp(buf_.data() + node, "SNOD", 4)) {
@@ -110,7 +139,14 @@ bool File::WalkGroupTree(uint64_t node, uint64_t heap_data, int depth, std::stri
       if (!In(name_at, 1)) return fail(err, "link name outside the heap");
       const char* s = (const char*)buf_.data() + name_at;
       const size_t maxlen = buf_.size() - name_at;
-      objects_[std::string(s, strnlen(s, maxlen))] = base_ + U(e + 8, 8);
+      const std::string name = prefix + std::string(s, strnlen(s, maxlen));
+      uint64_t sub_btree, sub_heap;
+      if (GroupOf(e, &sub_btree, &sub_heap)) {
+        groups_.push_back(name);
+        if (!WalkGroupTree(sub_btree, sub_heap, depth + 1, err, name + "/")) return false;
+      } else {
+        objects_[name] = base_ + U(e + 8, 8);
+      }
     }
     return true;
   }
@@ -119,7 +155,7 @@ bool File::WalkGroupTree(uint64_t node, uint64_t heap_data, int depth, std::stri
   if (!In(node + 24, (uint64_t)nent * 16 + 8)) return fail(err, "truncated group B-tree node");
   for (int i = 0; i < nent; ++i) {
     const uint64_t child = U(node + 24 + 8 + (uint64_t)i * 16, 8);   // key_i, child_i, key_{i+1}, ...
-    if (!WalkGroupTree(base_ + child, heap_data, depth + 1, err)) return false;
+    if (!WalkGroupTree(base_ + child, heap_data, depth + 1, err, prefix)) return false;
   }
   return true;
 }
@@ -418,16 +454,116 @@ struct Out {
 };
 }  // namespace
 
-bool WriteContiguous(const std::string& path, const std::vector<WriteDataset>& sets_in, std::string* err) {
-  std::vector<WriteDataset> sets(sets_in);
-  std::sort(sets.begin(), sets.end(), [](const WriteDataset& a, const WriteDataset& b) { return a.name < b.name; });
-  if (sets.empty() || sets.size() > 8) return fail(err, "WriteContiguous handles 1..8 datasets (one symbol node, K=4)");
+namespace {
+struct GroupNode {
+  std::map<std::string, const WriteDataset*> sets;    // leaf name -> dataset
+  std::map<std::string, GroupNode> groups;            // member groups
+};
+struct Emitted { uint64_t hdr, btree, heap; bool group; };
+
+Emitted emit_dataset(Out& o, const WriteDataset& d) {
+  o.pad8();
+  Emitted e{o.b.size(), 0, 0, false};
+  const int rank = (int)d.dims.size();
+  const uint64_t space = 8 + 8ull * rank, type = 8 + 12, layout = 24;
+  o.u(1, 1); o.u(0, 1); o.u(3, 2); o.u(1, 4); o.u((8 + space) + (8 + type + 4) + (8 + layout), 4); o.u(0, 4);
+  o.u(1, 2); o.u(space, 2); o.u(0, 1); o.u(0, 3);                 // dataspace v1, no max dims
+  o.u(1, 1); o.u(rank, 1); o.u(0, 1); o.u(0, 5);
+  for (int64_t x : d.dims) o.u((uint64_t)x, 8);
+  o.u(3, 2); o.u(type + 4, 2); o.u(1, 1); o.u(0, 3);              // datatype: IEEE float, LE (constant message)
+  o.u(0x11, 1); o.u(0x20, 1); o.u(d.elem_size == 4 ? 31 : 63, 1); o.u(0, 1); o.u(d.elem_size, 4);
+  if (d.elem_size == 4) { o.u(0, 2); o.u(32, 2); o.u(23, 1); o.u(8, 1); o.u(0, 1); o.u(23, 1); o.u(127, 4); }
+  else                  { o.u(0, 2); o.u(64, 2); o.u(52, 1); o.u(11, 1); o.u(0, 1); o.u(52, 1); o.u(1023, 4); }
+  o.u(0, 4);
+  o.u(8, 2); o.u(layout, 2); o.u(0, 1); o.u(0, 3);                // layout v3 contiguous
+  o.u(3, 1); o.u(1, 1);
+  const size_t addr_at = o.b.size(); o.u(0, 8);
+  const uint64_t bytes = (uint64_t)d.values.size() * d.elem_size;
+  o.u(bytes, 8); o.u(0, 6);
+  o.pad8();
+  o.patch(addr_at, o.b.size(), 8);
+  for (double v : d.values) {
+    if (d.elem_size == 4) { const float f = (float)v; uint32_t w; std::memcpy(&w, &f, 4); o.u(w, 4); }
+    else { uint64_t w; std::memcpy(&w, &v, 8); o.u(w, 8); }
+  }
+  return e;
+}
+
+// members first (their addresses are needed by the symbol node), then this group's object header (one
+// symbol-table message), local heap, one-leaf B-tree and symbol node (at most 8 members: K = 4)
+bool emit_group(Out& o, const GroupNode& g, Emitted* out, std::string* err) {
+  struct Member { std::string name; Emitted e; };
+  std::vector<Member> mem;
+  for (const auto& kv : g.sets) mem.push_back({kv.first, emit_dataset(o, *kv.second)});
+  for (const auto& kv : g.groups) {
+    Emitted e;
+    if (!emit_group(o, kv.second, &e, err)) return false;
+    mem.push_back({kv.first, e});
+  }
+  std::sort(mem.begin(), mem.end(), [](const Member& a, const Member& b) { return a.name < b.name; });
+  if (mem.empty() || mem.size() > 8) return fail(err, "the HDF5 writer handles 1..8 members per group (one symbol node, K=4)");
+  o.pad8();
+  Emitted me{o.b.size(), 0, 0, true};
+  o.u(1, 1); o.u(0, 1); o.u(1, 2); o.u(1, 4); o.u(24, 4); o.u(0, 4);
+  o.u(0x11, 2); o.u(16, 2); o.u(0, 1); o.u(0, 3);
+  const size_t stm_at = o.b.size(); o.u(0, 8); o.u(0, 8);
+  std::vector<uint64_t> name_off;
+  std::vector<uint8_t> heap(8, 0);                               // offset 0 is the empty string
+  for (const Member& m : mem) {
+    name_off.push_back(heap.size());
+    heap.insert(heap.end(), m.name.begin(), m.name.end());
+    heap.push_back(0);
+    while (heap.size() & 7) heap.push_back(0);
+  }
+  me.heap = o.b.size();
+  o.b.insert(o.b.end(), {'H', 'E', 'A', 'P'});
+  o.u(0, 1); o.u(0, 3); o.u(heap.size(), 8); o.u(kUndef, 8); o.u(me.heap + 32, 8);
+  o.b.insert(o.b.end(), heap.begin(), heap.end());
+  me.btree = o.b.size();
+  o.b.insert(o.b.end(), {'T', 'R', 'E', 'E'});
+  o.u(0, 1); o.u(0, 1); o.u(1, 2); o.u(kUndef, 8); o.u(kUndef, 8);
+  o.u(0, 8);
+  const size_t child_at = o.b.size(); o.u(0, 8);
+  o.u(name_off.back(), 8);
+  for (int i = 0; i < 2 * 16 - 1; ++i) { o.u(0, 8); o.u(0, 8); }   // unused key/child slots (2K = 32 entries)
+  o.patch(stm_at, me.btree, 8); o.patch(stm_at + 8, me.heap, 8);
+  o.patch(child_at, o.b.size(), 8);
+  o.b.insert(o.b.end(), {'S', 'N', 'O', 'D'});
+  o.u(1, 1); o.u(0, 1); o.u(mem.size(), 2);
+  for (size_t i = 0; i < 8; ++i) {
+    if (i < mem.size()) {
+      o.u(name_off[i], 8); o.u(mem[i].e.hdr, 8);
+      if (mem[i].e.group) { o.u(1, 4); o.u(0, 4); o.u(mem[i].e.btree, 8); o.u(mem[i].e.heap, 8); }
+      else { o.u(0, 4); o.u(0, 4); o.u(0, 8); o.u(0, 8); }
+    } else {
+      o.u(0, 8); o.u(0, 8); o.u(0, 4); o.u(0, 4); o.u(0, 8); o.u(0, 8);
+    }
+  }
+  *out = me;
+  return true;
+}
+}  // namespace
+
+// Dataset names may be paths ("data/sim/0"): the groups along the way are created (symbol-table groups, v1
+// object headers -- what libhdf5 1.8 writes by default and what Net::ToHDF5 produces, net.cpp:893-960).
+bool WriteContiguous(const std::string& path, const std::vector<WriteDataset>& sets, std::string* err) {
+  GroupNode root;
   for (const WriteDataset& d : sets) {
     int64_t c = 1;
     for (int64_t x : d.dims) c *= x;
-    if ((int64_t)d.values.size() != c || (d.elem_size != 4 && d.elem_size != 8) || d.name.empty())
+    if ((int64_t)d.values.size() != c || (d.elem_size != 4 && d.elem_size != 8) || d.name.empty() ||
+        d.name.front() == '/' || d.name.back() == '/')
       return fail(err, "bad dataset description: " + d.name);
+    GroupNode* g = &root;
+    size_t at = 0, slash;
+    while ((slash = d.name.find('/', at)) != std::string::npos) {
+      if (slash == at) return fail(err, "bad dataset path: " + d.name);
+      g = &g->groups[d.name.substr(at, slash - at)];
+      at = slash + 1;
+    }
+    if (!g->sets.emplace(d.name.substr(at), &d).second) return fail(err, "duplicate dataset: " + d.name);
   }
+  if (sets.empty()) return fail(err, "nothing to write");
   Out o;
   // superblock v0 (96 bytes incl. the root symbol table entry); addresses patched below
   o.b.insert(o.b.end(), kSignature, kSignature + 8);
@@ -440,72 +576,10 @@ bool WriteContiguous(const std::string& path, const std::vector<WriteDataset>& s
   const size_t root_hdr_at = o.b.size(); o.u(0, 8);
   o.u(1, 4); o.u(0, 4);                        // cache type 1: scratch = btree, heap
   const size_t scr_at = o.b.size(); o.u(0, 8); o.u(0, 8);
-  // root object header: one symbol-table message
-  o.patch(root_hdr_at, o.b.size(), 8);
-  o.u(1, 1); o.u(0, 1); o.u(1, 2); o.u(1, 4); o.u(24, 4); o.u(0, 4);
-  o.u(0x11, 2); o.u(16, 2); o.u(0, 1); o.u(0, 3);
-  const size_t stm_at = o.b.size(); o.u(0, 8); o.u(0, 8);
-  // local heap: names (offset 0 is the empty string)
-  std::vector<uint64_t> name_off;
-  std::vector<uint8_t> heap(8, 0);
-  for (const WriteDataset& d : sets) {
-    name_off.push_back(heap.size());
-    heap.insert(heap.end(), d.name.begin(), d.name.end());
-    heap.push_back(0);
-    while (heap.size() & 7) heap.push_back(0);
-  }
-  const uint64_t heap_addr = o.b.size();
-  o.b.insert(o.b.end(), {'H', 'E', 'A', 'P'});
-  o.u(0, 1); o.u(0, 3); o.u(heap.size(), 8); o.u(kUndef, 8); o.u(heap_addr + 32, 8);
-  o.b.insert(o.b.end(), heap.begin(), heap.end());
-  // B-tree with one leaf entry -> SNOD
-  const uint64_t btree_addr = o.b.size();
-  o.b.insert(o.b.end(), {'T', 'R', 'E', 'E'});
-  o.u(0, 1); o.u(0, 1); o.u(1, 2); o.u(kUndef, 8); o.u(kUndef, 8);
-  o.u(0, 8);
-  const size_t child_at = o.b.size(); o.u(0, 8);
-  o.u(name_off.back(), 8);
-  for (int i = 0; i < 2 * 16 - 1; ++i) { o.u(0, 8); o.u(0, 8); }   // unused key/child slots (2K = 32 entries)
-  o.patch(scr_at, btree_addr, 8); o.patch(scr_at + 8, heap_addr, 8);
-  o.patch(stm_at, btree_addr, 8); o.patch(stm_at + 8, heap_addr, 8);
-  const uint64_t snod_addr = o.b.size();
-  o.patch(child_at, snod_addr, 8);
-  o.b.insert(o.b.end(), {'S', 'N', 'O', 'D'});
-  o.u(1, 1); o.u(0, 1); o.u(sets.size(), 2);
-  std::vector<size_t> hdr_at;
-  for (size_t i = 0; i < 8; ++i) {
-    o.u(i < sets.size() ? name_off[i] : 0, 8);
-    hdr_at.push_back(o.b.size());
-    o.u(0, 8); o.u(0, 4); o.u(0, 4); o.u(0, 8); o.u(0, 8);
-  }
-  // dataset object headers + raw data
-  for (size_t i = 0; i < sets.size(); ++i) {
-    const WriteDataset& d = sets[i];
-    o.pad8();
-    o.patch(hdr_at[i], o.b.size(), 8);
-    const int rank = (int)d.dims.size();
-    const uint64_t space = 8 + 8ull * rank, type = 8 + 12, layout = 24;
-    o.u(1, 1); o.u(0, 1); o.u(3, 2); o.u(1, 4); o.u((8 + space) + (8 + type + 4) + (8 + layout), 4); o.u(0, 4);
-    o.u(1, 2); o.u(space, 2); o.u(0, 1); o.u(0, 3);                 // dataspace v1, no max dims
-    o.u(1, 1); o.u(rank, 1); o.u(0, 1); o.u(0, 5);
-    for (int64_t x : d.dims) o.u((uint64_t)x, 8);
-    o.u(3, 2); o.u(type + 4, 2); o.u(1, 1); o.u(0, 3);              // datatype: IEEE float, LE (constant message)
-    o.u(0x11, 1); o.u(0x20, 1); o.u(d.elem_size == 4 ? 31 : 63, 1); o.u(0, 1); o.u(d.elem_size, 4);
-    if (d.elem_size == 4) { o.u(0, 2); o.u(32, 2); o.u(23, 1); o.u(8, 1); o.u(0, 1); o.u(23, 1); o.u(127, 4); }
-    else                  { o.u(0, 2); o.u(64, 2); o.u(52, 1); o.u(11, 1); o.u(0, 1); o.u(52, 1); o.u(1023, 4); }
-    o.u(0, 4);
-    o.u(8, 2); o.u(layout, 2); o.u(0, 1); o.u(0, 3);                // layout v3 contiguous
-    o.u(3, 1); o.u(1, 1);
-    const size_t addr_at = o.b.size(); o.u(0, 8);
-    const uint64_t bytes = (uint64_t)d.values.size() * d.elem_size;
-    o.u(bytes, 8); o.u(0, 6);
-    o.pad8();
-    o.patch(addr_at, o.b.size(), 8);
-    for (double v : d.values) {
-      if (d.elem_size == 4) { const float f = (float)v; uint32_t w; std::memcpy(&w, &f, 4); o.u(w, 4); }
-      else { uint64_t w; std::memcpy(&w, &v, 8); o.u(w, 8); }
-    }
-  }
+  Emitted r;
+  if (!emit_group(o, root, &r, err)) return false;
+  o.patch(root_hdr_at, r.hdr, 8);
+  o.patch(scr_at, r.btree, 8); o.patch(scr_at + 8, r.heap, 8);
   o.patch(eof_at, o.b.size(), 8);
   FILE* f = std::fopen(path.c_str(), "wb");
   if (!f) return fail(err, "cannot write " + path);

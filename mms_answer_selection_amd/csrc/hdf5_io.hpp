@@ -36,7 +36,8 @@ class File {
  public:
   // Returns false and fills *err on any structural problem.
   bool Open(const std::string& path, std::string* err);
-  std::vector<std::string> DatasetNames() const;           // root-group members, name order
+  std::vector<std::string> DatasetNames() const;           // every dataset, "group/member" paths for nested ones, name order
+  const std::vector<std::string>& GroupNames() const { return groups_; }   // every group below the root, as paths
   bool Find(const std::string& name) const { return objects_.count(name) != 0; }
   bool Info(const std::string& name, DatasetInfo* info, std::string* err) const;
   // H5LTread_dataset_float: the whole dataset converted to float, row-major.
@@ -46,14 +47,16 @@ class File {
   struct Parsed;
   bool ParseObject(uint64_t addr, Parsed* p, std::string* err) const;
   bool ReadRaw(const Parsed& p, std::vector<uint8_t>* raw, std::string* err) const;
-  bool WalkGroupTree(uint64_t btree, uint64_t heap_data, int depth, std::string* err);
+  bool WalkGroupTree(uint64_t btree, uint64_t heap_data, int depth, std::string* err, const std::string& prefix = std::string());
+  bool GroupOf(uint64_t entry, uint64_t* btree, uint64_t* heap_data) const;
   bool WalkChunkTree(uint64_t node, const Parsed& p, std::vector<uint8_t>* raw, int depth, std::string* err) const;
   bool In(uint64_t off, uint64_t len) const { return off <= buf_.size() && len <= buf_.size() - off; }
   uint64_t U(uint64_t off, int bytes) const;
   std::vector<uint8_t> buf_;
   uint64_t base_ = 0;
   mutable uint64_t nodes_visited_ = 0;        // guards against cyclic B-trees in damaged files
-  std::map<std::string, uint64_t> objects_;   // dataset name -> object header address
+  std::map<std::string, uint64_t> objects_;   // dataset path -> object header address
+  std::vector<std::string> groups_;
 };
 
 // What h5py's `f[name] = ndarray` produces for a float32 / float64 array: a contiguous

@@ -85,6 +85,7 @@ _SIGNATURES = {
     "mms_snapshot_blob_count": (_i, [_vp, _i, _i]),
     "mms_snapshot_blob_data": (_fp, [_vp, _i, _i]),
     "mms_layer_copy_from_snapshot": (_i, [_vp, _vp, C.c_char_p]),
+    "mms_snapshot_writer_save_hdf5": (_i, [_vp, C.c_char_p, C.c_char_p, _i]),
     "mms_snapshot_writer_create": (_vp, [C.c_char_p]),
     "mms_snapshot_writer_destroy": (None, [_vp]),
     "mms_snapshot_writer_add_layer": (None, [_vp, C.c_char_p, C.c_char_p]),
@@ -376,7 +377,8 @@ def RankAccuracy(**kw):
 
 
 class Snapshot:
-    """A .caffemodel (binary NetParameter) opened for reading: {layer name: [numpy blobs]}."""
+    """A snapshot opened for reading -- .caffemodel (binary NetParameter, current or V1/V0 layer lists) or an
+    HDF5-format snapshot: {layer name: [numpy blobs]}."""
 
     def __init__(self, path):
         err = C.create_string_buffer(512)
@@ -419,8 +421,9 @@ class Snapshot:
         return True
 
 
-def save_snapshot(path, net_name, named_layers=(), raw_layers=()):
-    """Write a .caffemodel: `named_layers` = [(name, Layer)], `raw_layers` = [(name, type, [numpy blobs])]."""
+def save_snapshot(path, net_name, named_layers=(), raw_layers=(), hdf5=False):
+    """Write a .caffemodel (or, with hdf5=True, an HDF5-format snapshot): `named_layers` = [(name, Layer)],
+    `raw_layers` = [(name, type, [numpy blobs])]."""
     w = lib().mms_snapshot_writer_create(net_name.encode())
     try:
         for name, layer in named_layers:
@@ -431,7 +434,11 @@ def save_snapshot(path, net_name, named_layers=(), raw_layers=()):
                 b = np.ascontiguousarray(b, np.float32)
                 shp, n = _ints(b.shape)
                 lib().mms_snapshot_writer_add_blob(w, shp, n, b.ctypes.data_as(_fp))
-        if lib().mms_snapshot_writer_save(w, str(path).encode()):
+        if hdf5:
+            err = C.create_string_buffer(512)
+            if lib().mms_snapshot_writer_save_hdf5(w, str(path).encode(), err, 512):
+                raise IOError(err.value.decode())
+        elif lib().mms_snapshot_writer_save(w, str(path).encode()):
             raise IOError("cannot write %s" % path)
     finally:
         lib().mms_snapshot_writer_destroy(w)

@@ -135,7 +135,7 @@ def test_writer_round_trip_driver_format(tmp_path):
         assert (f[k] == v.astype(np.float32)).all()          # H5LTread_dataset_float: double -> float
     L.write_h5(p, {"x": np.arange(6, dtype=np.float32).reshape(2, 3)})
     assert L.H5File(p).info("x") == ((2, 3), 1, 4)
-    with pytest.raises(IOError, match="1..8 datasets"):
+    with pytest.raises(IOError, match="1..8 members"):
         L.write_h5(p, {"d%d" % i: np.zeros(2) for i in range(9)})
 
 

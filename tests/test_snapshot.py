@@ -40,9 +40,22 @@ def _caffe_messages():
                            ("top", 4, F.TYPE_STRING, R, False, None),
                            ("phase", 10, F.TYPE_INT32, O, False, None),
                            ("blobs", 7, F.TYPE_MESSAGE, R, False, "BlobProto")])
+    # pre-2015 formats (caffe.proto:1286-1345, 1355-1430): V1 `layers` with an enum type, V0 nested in `layer`
+    msg("V0LayerParameter", [("name", 1, F.TYPE_STRING, O, False, None),
+                             ("type", 2, F.TYPE_STRING, O, False, None),
+                             ("num_output", 3, F.TYPE_UINT32, O, False, None),
+                             ("blobs", 50, F.TYPE_MESSAGE, R, False, "BlobProto")])
+    msg("V1LayerParameter", [("bottom", 2, F.TYPE_STRING, R, False, None),
+                             ("top", 3, F.TYPE_STRING, R, False, None),
+                             ("name", 4, F.TYPE_STRING, O, False, None),
+                             ("type", 5, F.TYPE_INT32, O, False, None),
+                             ("blobs", 6, F.TYPE_MESSAGE, R, False, "BlobProto"),
+                             ("blobs_lr", 7, F.TYPE_FLOAT, R, False, None),
+                             ("layer", 1, F.TYPE_MESSAGE, O, False, "V0LayerParameter")])
     msg("NetParameter", [("name", 1, F.TYPE_STRING, O, False, None),
                          ("input", 3, F.TYPE_STRING, R, False, None),
                          ("force_backward", 5, F.TYPE_BOOL, O, False, None),
+                         ("layers", 2, F.TYPE_MESSAGE, R, False, "V1LayerParameter"),
                          ("layer", 100, F.TYPE_MESSAGE, R, False, "LayerParameter")])
     pool = descriptor_pool.DescriptorPool()
     pool.Add(fd)
@@ -103,6 +116,66 @@ def test_reader_legacy_4d_and_double_blobs(tmp_path):
     assert blobs[0].shape == (1, 1, 3, 4) and (blobs[0].ravel() == x).all()
     assert blobs[1].shape == (2, 2)
     assert (blobs[1].ravel() == np.array([1.5, -2.25, 3.0, 1e-3], np.float32)).all()
+
+
+def test_reader_v1_and_v0_layer_lists(tmp_path):
+    """Pre-2015 snapshots: NetParameter.layers (V1LayerParameter: enum type, blobs = 6), one of them wrapping a
+    V0LayerParameter (name / type / blobs = 50 inside `layer`).  Names, upgraded type strings and blob bits."""
+    r = np.random.default_rng(3)
+    Net = _caffe_messages()
+    net = Net(name="old_net")
+    w1 = r.standard_normal((10, 6)).astype(np.float32)
+    b1 = r.standard_normal((10,)).astype(np.float32)
+    l = net.layers.add(name="ip1", type=14)                       # INNER_PRODUCT
+    l.bottom.append("data"); l.top.append("ip1"); l.blobs_lr.extend([1.0, 2.0])
+    for x in (w1, b1):
+        b = l.blobs.add()
+        b.shape.dim.extend(x.shape)
+        b.data.extend(x.ravel().tolist())
+    net.layers.add(name="relu1", type=18)                         # RELU, no blobs
+    w0 = r.standard_normal((1, 1, 4, 5)).astype(np.float32)
+    v = net.layers.add()                                          # a V0 layer in its V1 wrapper
+    v.bottom.append("x"); v.top.append("y")
+    v.layer.name = "conv_v0"; v.layer.type = "conv"; v.layer.num_output = 4
+    b = v.layer.blobs.add(num=1, channels=1, height=4, width=5)
+    b.data.extend(w0.ravel().tolist())
+    net.layers.add(name="future", type=77)                        # an enum value this table does not know
+    p = tmp_path / "old.caffemodel"
+    p.write_bytes(net.SerializeToString())
+    got = L.Snapshot(p).layers()
+    assert [(n, t, len(bl)) for n, t, bl in got] == [("ip1", "InnerProduct", 2), ("relu1", "ReLU", 0),
+                                                     ("conv_v0", "conv", 1), ("future", "", 0)]
+    assert got[0][2][0].shape == (10, 6) and (got[0][2][0].view(np.uint32) == w1.view(np.uint32)).all()
+    assert (got[0][2][1] == b1).all()
+    assert got[2][2][0].shape == (1, 1, 4, 5) and (got[2][2][0] == w0).all()
+
+
+def test_hdf5_snapshot_round_trip(tmp_path):
+    """snapshot_format HDF5: /data/<layer>/<index> float datasets (Net::ToHDF5 / CopyTrainedLayersFromHDF5)."""
+    r = np.random.default_rng(5)
+    raw = [("sim", "SimCross", [r.standard_normal((4, 7, 7)).astype(np.float32),
+                                r.standard_normal((4, 3, 2)).astype(np.float32)]),
+           ("relu", "ReLU", []),
+           ("embed", "Embed", [r.standard_normal((300, 50)).astype(np.float32)]),
+           ("simm", "SimMatrix", [r.standard_normal((12, 12)).astype(np.float32)])]
+    p = tmp_path / "qa_iter_10.caffemodel.h5"
+    L.save_snapshot(p, "qa", raw_layers=raw, hdf5=True)
+    h = L.H5File(p)                                               # the file itself: nested groups, dataset paths
+    assert h.keys() == sorted(["data/embed/0", "data/sim/0", "data/sim/1", "data/simm/0"])
+    assert h.info("data/sim/1") == ((4, 3, 2), 1, 4)
+    got = {n: (t, bl) for n, t, bl in L.Snapshot(p).layers()}   # and as a snapshot (types are not stored)
+    assert sorted(got) == ["embed", "sim", "simm"]
+    for name, _, blobs in raw:
+        if not blobs:
+            continue
+        t, gb = got[name]
+        assert t == "" and len(gb) == len(blobs)
+        for g, w in zip(gb, blobs):
+            assert g.shape == w.shape and (g.view(np.uint32) == w.view(np.uint32)).all()
+    bad = tmp_path / "feed.h5"                                    # an HDF5 file that is not a snapshot
+    L.write_h5(bad, {"question": np.zeros((2, 3))})
+    with pytest.raises(IOError, match="no /data group"):
+        L.Snapshot(bad)
 
 
 def test_writer_parsed_by_protobuf_runtime(tmp_path):
@@ -206,6 +279,17 @@ def test_copy_trained_layers_into_simcross_and_back(tmp_path):
     lay.Forward([bq, ba], [bt])
     ref, _, _ = O.simcross_forward(2, q, a, W, bias)
     np.testing.assert_allclose(bt.data, ref, rtol=1e-5, atol=1e-5)
+
+    # the same parameters from an HDF5-format snapshot (Net::CopyTrainedLayersFromHDF5)
+    h5 = tmp_path / "qa.caffemodel.h5"
+    L.save_snapshot(h5, "qa", raw_layers=[("sim", "SimCross", [W * 2, bias * 2]), ("sim_bad_shape", "SimCross", [W[:, :, :6], bias])],
+                    hdf5=True)
+    snap5 = L.Snapshot(h5)
+    assert snap5.copy_into(lay, "sim") is True
+    assert (lay.blobs[0].data == W * 2).all() and (lay.blobs[1].data == bias * 2).all()
+    with pytest.raises(ValueError, match="blob shape"):
+        snap5.copy_into(lay, "sim_bad_shape")
+    assert snap.copy_into(lay, "sim") is True                       # back to the .caffemodel's values
 
     out = tmp_path / "out.caffemodel"
     L.save_snapshot(out, "qa", named_layers=[("sim", lay)])
