@@ -2,9 +2,13 @@
 //
 // The reference instantiates every layer for float AND double
 // (INSTANTIATE_CLASS, include/caffe/common.hpp:41-44).  fp64 is not where this
-// workload lives (the driver trains in float), so these kernels are FUNCTIONAL,
-// not tuned: one thread per output element, the reference's loop order inside
-// it, grid-stride over the outputs.  What they guarantee is the numerics:
+// workload lives (the driver trains in float).  The order-defined paths (Euclid,
+// PairRankLoss, dbias) are FUNCTIONAL kernels: one thread per output element, the
+// reference's loop order inside it, grid-stride over the outputs.  Round 2: every
+// GEMM-shaped product of the bilinear mode and of SimMatrix runs on the fp64 matrix
+// pipe (gemm64_kernel below, v_mfma_f64_16x16x4_f64: each MFMA is an fmaf chain in
+// double, no reduced precision) -- 16384 x 300 x 300 SimMatrix forward 1394 -> 122 us,
+// backward 11.6 ms -> 0.59 ms; the driver's 50 x 40 x 40 x 50 M = 4 bilinear backward 671 -> 133 us.  What they guarantee is the numerics:
 //   * Euclidean forward / backward and PairRankLoss elementwise terms and the
 //     bilinear dbias: the reference's operation order => bit-identical to the
 //     CPU code (-ffp-contract=off, IEEE f64 sqrt / divide);
@@ -92,109 +96,232 @@ __global__ __launch_bounds__(kT) void d_cross_bwd(int N, int W1, int W2, int D, 
   }
 }
 
+// ---------------------------------------------------------------- fp64 GEMM on the matrix pipe
+// C[b0,b1] (M x N) (+)= epilogue( sum_{seg, kk} A[m, (seg,kk)] * B[(seg,kk), n] )
+//   * any element strides for A and B (row- or column-major operands, transposes are strides); the threads
+//     that stage a tile run along whichever stride is 1, so both layouts load coalesced;
+//   * K = nseg segments of L: segment `seg` of A / B starts a_seg / b_seg elements further on (the sums over
+//     pairs n or measures m of the bilinear backward are ONE product with a segmented K);
+//   * two batch indices (b0 = blockIdx.z / nb1, b1 = blockIdx.z % nb1) with separate strides for A, B, C, the
+//     bias matrix and the row-scale vector (A varies with the pair only, W with the measure only, ...);
+//   * epilogue: acc *= rowscale[m] (SimMatrix's dT_i), acc = bias[m,n] + acc (:155-159), C = acc or C += acc;
+//   * kscale[k]: A[m,k] is multiplied by kscale[k] as it is staged ((dT_i q[i,r]) of sim_matrix_layer.cpp:75-78).
+// 64 x 64 tile per workgroup of four waves (32 x 32 = 2 x 2 MFMA blocks each), K tiles of 16 through LDS.
+struct G64 {
+  int M, N, L, nseg;
+  const double* A; i64 sam, sak, a_seg, a_b0, a_b1;
+  const double* B; i64 sbk, sbn, b_seg, b_b0, b_b1;
+  double* C; i64 ldc, c_b0, c_b1;
+  int nb1, beta;
+  const double* rowscale; i64 rs_b0;
+  const double* kscale;
+  const double* bias; i64 ldbias, bias_b1;
+};
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int G64_T = 64, G64_K = 16, G64_LS = G64_T + 4;
+
+__global__ __launch_bounds__(256) void gemm64_kernel(G64 g) {
+  __shared__ double As[G64_K * G64_LS];             // [k][m]
+  __shared__ double Bs[G64_K * G64_LS];             // [k][n]
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int b0 = blockIdx.z / g.nb1, b1 = blockIdx.z - b0 * g.nb1;
+  const int m0 = blockIdx.y * G64_T, n0 = blockIdx.x * G64_T;
+  const double* A = g.A + b0 * g.a_b0 + b1 * g.a_b1;
+  const double* B = g.B + b0 * g.b_b0 + b1 * g.b_b1;
+  // staging maps: the fastest thread index follows the unit stride
+  const bool a_kfast = (g.sak == 1), b_nfast = (g.sbn == 1) || (g.sbk != 1);
+  const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+  const int li = lane & 15, lg = lane >> 4;
+  v4d acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  // K tiles in order (seg major): tile i+1's global loads are issued before tile i's MFMAs
+  const int tiles_per_seg = (g.L + G64_K - 1) / G64_K, ntiles = g.nseg * tiles_per_seg;
+  double va[4], vb[4];
+  auto fetch = [&](int tile) {
+    const int seg = tile / tiles_per_seg, k0 = (tile - seg * tiles_per_seg) * G64_K;
+    const double* As_g = A + seg * g.a_seg;
+    const double* Bs_g = B + seg * g.b_seg;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = t + 256 * u;
+      const int kk = a_kfast ? (e & 15) : (e >> 6), mm = a_kfast ? (e >> 4) : (e & 63);
+      const int k = k0 + kk, m = m0 + mm;
+      const bool ok = k < g.L && m < g.M;
+      double v = As_g[(i64)(ok ? m : 0) * g.sam + (i64)(ok ? k : 0) * g.sak];
+      if (g.kscale) v = g.kscale[seg * (i64)g.L + (ok ? k : 0)] * v;
+      va[u] = ok ? v : 0.0;
+      const int kb = b_nfast ? (e >> 6) : (e & 15), nn = b_nfast ? (e & 63) : (e >> 4);
+      const int k2 = k0 + kb, n = n0 + nn;
+      const bool ok2 = k2 < g.L && n < g.N;
+      const double w = Bs_g[(i64)(ok2 ? k2 : 0) * g.sbk + (i64)(ok2 ? n : 0) * g.sbn];
+      vb[u] = ok2 ? w : 0.0;
+    }
+  };
+  fetch(0);
+  for (int tile = 0; tile < ntiles; ++tile) {
+    __syncthreads();                                 // the previous tile's MFMAs have read As / Bs
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = t + 256 * u;
+      As[(a_kfast ? (e & 15) : (e >> 6)) * G64_LS + (a_kfast ? (e >> 4) : (e & 63))] = va[u];
+      Bs[(b_nfast ? (e >> 6) : (e & 15)) * G64_LS + (b_nfast ? (e & 63) : (e >> 4))] = vb[u];
+    }
+    __syncthreads();
+    if (tile + 1 < ntiles) fetch(tile + 1);
+#pragma unroll
+    for (int ks = 0; ks < G64_K; ks += 4) {
+      double a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = As[(ks + lg) * G64_LS + wm + 16 * i + li];
+        b[i] = Bs[(ks + lg) * G64_LS + wn + 16 * i + li];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  double* C = g.C + b0 * g.c_b0 + b1 * g.c_b1;
+  const double* rs = g.rowscale ? g.rowscale + b0 * g.rs_b0 : nullptr;
+  const double* bias = g.bias ? g.bias + b1 * g.bias_b1 : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // D layout of v_mfma_f64_16x16x4_f64: register r of lane l holds row 4*r + l/16, column l%16 (four groups
+        // of one row per lane -- unlike the fp32 16x16x4, whose lanes hold four CONSECUTIVE rows)
+        const int m = m0 + wm + 16 * i + 4 * r + lg, n = n0 + wn + 16 * j + li;
+        if (m < g.M && n < g.N) {
+          double v = acc[i][j][r];
+          if (rs) v = rs[m] * v;
+          if (bias) v = bias[(i64)m * g.ldbias + n] + v;
+          double* c = C + (i64)m * g.ldc + n;
+          *c = g.beta ? *c + v : v;
+        }
+      }
+}
+
+// The same product for SMALL outputs with a LONG inner dimension (SimMatrix's dW: 300 x 300 from K = 16384 rows;
+// the bilinear dW: D x D from K = N*W2): a 64 x 64 tiling gives 25 workgroups that each walk 1024 K tiles one
+// memory round trip at a time (3.1 ms).  Here a workgroup of SIXTEEN waves owns a 32 x 32 tile and every wave
+// walks its own interleaved share of K, operands straight from global memory into the MFMA registers (no LDS,
+// no barrier in the loop, sixteen independent load streams per tile); the sixteen partial tiles are then added
+// in wave order through LDS -- a fixed order, so the result is deterministic.
+constexpr int G64_TK = 32, G64_TKW = 16;
+__global__ __launch_bounds__(64 * G64_TKW) void gemm64_tallk_kernel(G64 g) {
+  __shared__ double red[G64_TK * G64_TK];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int b0 = blockIdx.z / g.nb1, b1 = blockIdx.z - b0 * g.nb1;
+  const int m0 = blockIdx.y * G64_TK, n0 = blockIdx.x * G64_TK;
+  const double* A = g.A + b0 * g.a_b0 + b1 * g.a_b1;
+  const double* B = g.B + b0 * g.b_b0 + b1 * g.b_b1;
+  const int li = lane & 15, lg = lane >> 4;
+  const i64 Ktot = (i64)g.nseg * g.L;
+  v4d acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  const int mi[2] = {m0 + li, m0 + 16 + li}, ni[2] = {n0 + li, n0 + 16 + li};
+  constexpr int UN = 4;                              // k steps in flight per wave
+  for (i64 base = (i64)wave * 4 * UN; base < Ktot; base += (i64)G64_TKW * 4 * UN) {
+    double a[UN][2], b[UN][2];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const i64 kf = base + 4 * u + lg;
+      const bool kok = kf < Ktot;
+      const i64 seg = kok ? kf / g.L : 0, kk = kok ? kf - seg * g.L : 0;
+      const double ks = (g.kscale && kok) ? g.kscale[kf] : 1.0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool ok = kok && mi[i] < g.M;
+        const double v = A[(i64)(ok ? mi[i] : 0) * g.sam + seg * g.a_seg + kk * g.sak];
+        a[u][i] = ok ? (g.kscale ? ks * v : v) : 0.0;
+        const bool ok2 = kok && ni[i] < g.N;
+        const double w = B[seg * g.b_seg + kk * g.sbk + (i64)(ok2 ? ni[i] : 0) * g.sbn];
+        b[u][i] = ok2 ? w : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+  }
+  for (int w = 0; w < G64_TKW; ++w) {                // partial tiles added in wave order
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = (16 * i + 4 * r + lg) * G64_TK + 16 * j + li;
+            red[e] = (w == 0) ? acc[i][j][r] : red[e] + acc[i][j][r];
+          }
+    }
+    __syncthreads();
+  }
+  double* C = g.C + b0 * g.c_b0 + b1 * g.c_b1;
+  const double* rs = g.rowscale ? g.rowscale + b0 * g.rs_b0 : nullptr;
+  const double* bias = g.bias ? g.bias + b1 * g.bias_b1 : nullptr;
+  {
+    const int e = t;                                 // 1024 threads, 1024 outputs
+    const int m = m0 + e / G64_TK, n = n0 + e % G64_TK;
+    if (m < g.M && n < g.N) {
+      double v = red[e];
+      if (rs) v = rs[m] * v;
+      if (bias) v = bias[(i64)m * g.ldbias + n] + v;
+      double* c = C + (i64)m * g.ldc + n;
+      *c = g.beta ? *c + v : v;
+    }
+  }
+}
+
+inline G64 g64(int M, int N, int K, const double* A, i64 sam, i64 sak, const double* B, i64 sbk, i64 sbn,
+               double* C, i64 ldc) {
+  G64 g{};
+  g.M = M; g.N = N; g.L = K; g.nseg = 1;
+  g.A = A; g.sam = sam; g.sak = sak;
+  g.B = B; g.sbk = sbk; g.sbn = sbn;
+  g.C = C; g.ldc = ldc; g.nb1 = 1;
+  return g;
+}
+inline void run_g64(const G64& g, int nb0, hipStream_t s) {
+  const i64 tiles64 = (i64)((g.N + G64_T - 1) / G64_T) * ((g.M + G64_T - 1) / G64_T) * nb0 * g.nb1;
+  if ((i64)g.nseg * g.L >= 1024 && tiles64 <= 64) {  // small output, long K: sixteen K streams per tile
+    const dim3 gr((unsigned)((g.N + G64_TK - 1) / G64_TK), (unsigned)((g.M + G64_TK - 1) / G64_TK),
+                  (unsigned)(nb0 * g.nb1));
+    hipLaunchKernelGGL(gemm64_tallk_kernel, gr, dim3(64 * G64_TKW), 0, s, g);
+    return;
+  }
+  const dim3 grid((unsigned)((g.N + G64_T - 1) / G64_T), (unsigned)((g.M + G64_T - 1) / G64_T),
+                  (unsigned)(nb0 * g.nb1));
+  hipLaunchKernelGGL(gemm64_kernel, grid, dim3(256), 0, s, g);
+}
+
+// top[i] = sum_c a[i,c] scratch[i,c], c ascending within a lane, lanes summed in a fixed tree: one wave per row
+__global__ __launch_bounds__(kT) void d_sm_top_wave(int N, int K2, const double* __restrict__ a,
+                                                    const double* __restrict__ scratch, double* __restrict__ top) {
+  const i64 row = (i64)blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const int lane = threadIdx.x & 63;
+  double s = 0;
+  for (int c = lane; c < K2; c += 64) s += a[row * K2 + c] * scratch[row * K2 + c];
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) top[row] = s;
+}
+
 // ---------------------------------------------------------------- SimCross mode 2 (bilinear)
-// tmp[n,m,j,e] = sum_d Q[n,j,d] W[m,d,e]
-__global__ __launch_bounds__(kT) void d_qw(int N, int M, int W1, int D, const double* __restrict__ q,
-                                           const double* __restrict__ W, double* __restrict__ tmp) {
-  const i64 total = (i64)N * M * W1 * D;
-  MMS_GRID_LOOP(x, total) {
-    const int e = (int)(x % D), j = (int)((x / D) % W1), m = (int)((x / ((i64)D * W1)) % M);
-    const i64 n = x / ((i64)D * W1 * M);
-    const double* qr = q + (n * W1 + j) * D;
-    const double* w = W + (i64)m * D * D + e;
-    double s = 0;
-    for (int d = 0; d < D; ++d) s += qr[d] * w[(i64)d * D];
-    tmp[x] = s;
-  }
-}
-// top[n,m,j,k] = sum_e tmp[n,m,j,e] A[n,k,e] (+ bias[m,j,k])
-__global__ __launch_bounds__(kT) void d_bil_top(int N, int M, int W1, int W2, int D, const double* __restrict__ tmp,
-                                                const double* __restrict__ a, const double* __restrict__ bias,
-                                                double* __restrict__ top) {
-  const i64 total = (i64)N * M * W1 * W2;
-  MMS_GRID_LOOP(t, total) {
-    const int k = (int)(t % W2), j = (int)((t / W2) % W1), m = (int)((t / ((i64)W2 * W1)) % M);
-    const i64 n = t / ((i64)W2 * W1 * M);
-    const double* r = tmp + ((n * M + m) * W1 + j) * D;
-    const double* ar = a + (n * W2 + k) * D;
-    double s = 0;
-    for (int e = 0; e < D; ++e) s += r[e] * ar[e];
-    top[t] = bias ? bias[((i64)m * W1 + j) * W2 + k] + s : s;       // :155-159
-  }
-}
-// t1[n,m,d,k] = sum_j Q[n,j,d] dT[n,m,j,k]
-__global__ __launch_bounds__(kT) void d_qt_dt(int N, int M, int W1, int W2, int D, const double* __restrict__ q,
-                                              const double* __restrict__ dT, double* __restrict__ t1) {
-  const i64 total = (i64)N * M * D * W2;
-  MMS_GRID_LOOP(x, total) {
-    const int k = (int)(x % W2), d = (int)((x / W2) % D), m = (int)((x / ((i64)W2 * D)) % M);
-    const i64 n = x / ((i64)W2 * D * M);
-    double s = 0;
-    for (int j = 0; j < W1; ++j) s += q[(n * W1 + j) * D + d] * dT[((n * M + m) * W1 + j) * W2 + k];
-    t1[x] = s;
-  }
-}
-// dW[m,d,e] = sum_n sum_k t1[n,m,d,k] A[n,k,e]   (W.diff is overwritten: :256 zeroes it first)
-__global__ __launch_bounds__(kT) void d_dw(int N, int M, int W2, int D, const double* __restrict__ t1,
-                                           const double* __restrict__ a, double* __restrict__ dW) {
-  const i64 total = (i64)M * D * D;
-  MMS_GRID_LOOP(x, total) {
-    const int e = (int)(x % D), d = (int)((x / D) % D), m = (int)(x / ((i64)D * D));
-    double acc = 0;
-    for (i64 n = 0; n < N; ++n) {
-      double s = 0;
-      for (int k = 0; k < W2; ++k) s += t1[((n * M + m) * D + d) * W2 + k] * a[(n * W2 + k) * D + e];
-      acc = s + acc;                                                 // gemm beta = 1, n ascending
-    }
-    dW[x] = acc;
-  }
-}
-// t2[n,m,d,k] = sum_e W[m,d,e] A[n,k,e]
-__global__ __launch_bounds__(kT) void d_w_at(int N, int M, int W2, int D, const double* __restrict__ W,
-                                             const double* __restrict__ a, double* __restrict__ t2) {
-  const i64 total = (i64)N * M * D * W2;
-  MMS_GRID_LOOP(x, total) {
-    const int k = (int)(x % W2), d = (int)((x / W2) % D), m = (int)((x / ((i64)W2 * D)) % M);
-    const i64 n = x / ((i64)W2 * D * M);
-    const double* w = W + ((i64)m * D + d) * D;
-    const double* ar = a + (n * W2 + k) * D;
-    double s = 0;
-    for (int e = 0; e < D; ++e) s += w[e] * ar[e];
-    t2[x] = s;
-  }
-}
-// dq[n,j,d] = sum_m sum_k dT[n,m,j,k] t2[n,m,d,k]
-__global__ __launch_bounds__(kT) void d_bil_dq(int N, int M, int W1, int W2, int D, const double* __restrict__ dT,
-                                               const double* __restrict__ t2, double* __restrict__ dq) {
-  const i64 total = (i64)N * W1 * D;
-  MMS_GRID_LOOP(x, total) {
-    const int d = (int)(x % D), j = (int)((x / D) % W1);
-    const i64 n = x / ((i64)D * W1);
-    double acc = 0;
-    for (int m = 0; m < M; ++m) {
-      double s = 0;
-      for (int k = 0; k < W2; ++k) s += dT[((n * M + m) * W1 + j) * W2 + k] * t2[((n * M + m) * D + d) * W2 + k];
-      acc = s + acc;
-    }
-    dq[x] = acc;
-  }
-}
-// da[n,k,e] = sum_m sum_j dT[n,m,j,k] tmp[n,m,j,e]
-__global__ __launch_bounds__(kT) void d_bil_da(int N, int M, int W1, int W2, int D, const double* __restrict__ dT,
-                                               const double* __restrict__ tmp, double* __restrict__ da) {
-  const i64 total = (i64)N * W2 * D;
-  MMS_GRID_LOOP(x, total) {
-    const int e = (int)(x % D), k = (int)((x / D) % W2);
-    const i64 n = x / ((i64)D * W2);
-    double acc = 0;
-    for (int m = 0; m < M; ++m) {
-      double s = 0;
-      for (int j = 0; j < W1; ++j) s += dT[((n * M + m) * W1 + j) * W2 + k] * tmp[((n * M + m) * W1 + j) * D + e];
-      acc = s + acc;
-    }
-    da[x] = acc;
-  }
-}
 // dbias[m,j,k] = dT[n,m,j,k] + dbias, n ascending (:301-304: accumulated into the existing diff)
 __global__ __launch_bounds__(kT) void d_dbias(int N, i64 per, const double* __restrict__ dT, double* __restrict__ dbias) {
   MMS_GRID_LOOP(x, per) {
@@ -205,55 +332,6 @@ __global__ __launch_bounds__(kT) void d_dbias(int N, i64 per, const double* __re
 }
 __global__ __launch_bounds__(kT) void d_fill0(double* __restrict__ p, i64 n) {
   MMS_GRID_LOOP(i, n) p[i] = 0;
-}
-
-// ---------------------------------------------------------------- SimMatrix
-// scratch[i,c] = sum_r Q[i,r] W[r,c]
-__global__ __launch_bounds__(kT) void d_sm_qw(int N, int K1, int K2, const double* __restrict__ q,
-                                              const double* __restrict__ W, double* __restrict__ scratch) {
-  const i64 total = (i64)N * K2;
-  MMS_GRID_LOOP(x, total) {
-    const int c = (int)(x % K2);
-    const i64 i = x / K2;
-    double s = 0;
-    for (int r = 0; r < K1; ++r) s += q[i * K1 + r] * W[(i64)r * K2 + c];
-    scratch[x] = s;
-  }
-}
-__global__ __launch_bounds__(kT) void d_sm_top(int N, int K2, const double* __restrict__ a,
-                                               const double* __restrict__ scratch, double* __restrict__ top) {
-  MMS_GRID_LOOP(i, (i64)N) {
-    double s = 0;
-    for (int c = 0; c < K2; ++c) s += a[i * K2 + c] * scratch[i * K2 + c];
-    top[i] = s;
-  }
-}
-// dW[r,c] += sum_i (dT_i q[i,r]) a[i,c], i ascending (N sger's, :75-78)
-__global__ __launch_bounds__(kT) void d_sm_dw(int N, int K1, int K2, const double* __restrict__ q,
-                                              const double* __restrict__ a, const double* __restrict__ dT,
-                                              double* __restrict__ dW) {
-  const i64 total = (i64)K1 * K2;
-  MMS_GRID_LOOP(x, total) {
-    const int c = (int)(x % K2), r = (int)(x / K2);
-    double acc = dW[x];
-    for (i64 i = 0; i < N; ++i) acc += (dT[i] * q[i * K1 + r]) * a[i * K2 + c];
-    dW[x] = acc;
-  }
-}
-// SIDE 0: dq[i,r] = dT_i * sum_c W[r,c] a[i,c];  SIDE 1: da[i,c] = dT_i * sum_r W[r,c] q[i,r]
-template <int SIDE>
-__global__ __launch_bounds__(kT) void d_sm_dx(int N, int K1, int K2, const double* __restrict__ x,
-                                              const double* __restrict__ W, const double* __restrict__ dT,
-                                              double* __restrict__ out) {
-  const int Ko = SIDE ? K2 : K1, Ki = SIDE ? K1 : K2;
-  const i64 total = (i64)N * Ko;
-  MMS_GRID_LOOP(e, total) {
-    const int o = (int)(e % Ko);
-    const i64 i = e / Ko;
-    double s = 0;
-    for (int u = 0; u < Ki; ++u) s += (SIDE ? W[(i64)u * K2 + o] : W[(i64)o * K2 + u]) * x[i * Ki + u];
-    out[e] = dT[i] * s;
-  }
 }
 
 // ---------------------------------------------------------------- PairRankLoss
@@ -304,6 +382,16 @@ __global__ __launch_bounds__(kT) void d_pair_bwd(int count, double s0, double s1
 
 }  // namespace
 
+// tmp[n,m] (W1 x D) = Q_n (W1 x D) . W_m (D x D)
+static void bil_qw(int N, int M, int W1, int D, const double* q, const double* W, double* tmp, hipStream_t s) {
+  G64 g = g64(W1, D, D, q, D, 1, W, D, 1, tmp, D);
+  g.nb1 = M;
+  g.a_b0 = (i64)W1 * D;
+  g.b_b1 = (i64)D * D;
+  g.c_b0 = (i64)M * W1 * D; g.c_b1 = (i64)W1 * D;
+  run_g64(g, N, s);
+}
+
 size_t simcross_workspace_bytes_f64(int mode, int N, int W1, int W2, int D, int M) {
   if (mode != 2) return 0;
   const size_t wmax = (size_t)(W1 > W2 ? W1 : W2);
@@ -323,8 +411,15 @@ int simcross_forward_f64(int mode, int N, int W1, int W2, int D, int M, const do
   } else {
     if (!ws || ws_bytes < simcross_workspace_bytes_f64(2, N, W1, W2, D, M)) return MMS_ERR_WORKSPACE;
     double* tmp = static_cast<double*>(ws);
-    L(d_qw, (i64)N * M * W1 * D, N, M, W1, D, q, W, tmp);
-    L(d_bil_top, (i64)N * M * W1 * W2, N, M, W1, W2, D, tmp, a, bias, top);
+    bil_qw(N, M, W1, D, q, W, tmp, s);
+    // top[n,m] (W1 x W2) = tmp[n,m] (W1 x D) . A_n^T (+ bias[m])
+    G64 g = g64(W1, W2, D, tmp, D, 1, a, 1, D, top, W2);
+    g.nb1 = M;
+    g.a_b0 = (i64)M * W1 * D; g.a_b1 = (i64)W1 * D;
+    g.b_b0 = (i64)W2 * D;
+    g.c_b0 = (i64)M * W1 * W2; g.c_b1 = (i64)W1 * W2;
+    g.bias = bias; g.ldbias = W2; g.bias_b1 = (i64)W1 * W2;
+    run_g64(g, N, s);
   }
   return launch_status();
 }
@@ -350,12 +445,42 @@ int simcross_backward_f64(int mode, int N, int W1, int W2, int D, int M, const d
     const size_t wmax = (size_t)(W1 > W2 ? W1 : W2);
     double* tmp = static_cast<double*>(ws);
     double* t12 = tmp + (size_t)N * M * wmax * D;
-    L(d_qt_dt, (i64)N * M * D * W2, N, M, W1, W2, D, q, top_diff, t12);
-    L(d_dw, (i64)M * D * D, N, M, W2, D, t12, a, dW);
-    L(d_w_at, (i64)N * M * D * W2, N, M, W2, D, W, a, t12);
-    L(d_bil_dq, (i64)N * W1 * D, N, M, W1, W2, D, top_diff, t12, dq);
-    L(d_qw, (i64)N * M * W1 * D, N, M, W1, D, q, W, tmp);
-    L(d_bil_da, (i64)N * W2 * D, N, M, W1, W2, D, top_diff, tmp, da);
+    {  // t1[n,m] (D x W2) = Q_n^T (D x W1) . dT[n,m] (W1 x W2)
+      G64 g = g64(D, W2, W1, q, 1, D, top_diff, W2, 1, t12, W2);
+      g.nb1 = M;
+      g.a_b0 = (i64)W1 * D;
+      g.b_b0 = (i64)M * W1 * W2; g.b_b1 = (i64)W1 * W2;
+      g.c_b0 = (i64)M * D * W2; g.c_b1 = (i64)D * W2;
+      run_g64(g, N, s);
+    }
+    {  // dW[m] (D x D) = sum_n t1[n,m] (D x W2) . A_n (W2 x D): K = N segments of W2   (:256 zeroes W.diff first)
+      G64 g = g64(D, D, W2, t12, W2, 1, a, D, 1, dW, D);
+      g.nseg = N; g.a_seg = (i64)M * D * W2; g.b_seg = (i64)W2 * D;
+      g.a_b0 = (i64)D * W2;                           // b0 = measure m
+      g.c_b0 = (i64)D * D;
+      run_g64(g, M, s);
+    }
+    {  // t2[n,m] (D x W2) = W_m (D x D) . A_n^T
+      G64 g = g64(D, W2, D, W, D, 1, a, 1, D, t12, W2);
+      g.nb1 = M;
+      g.a_b1 = (i64)D * D;
+      g.b_b0 = (i64)W2 * D;
+      g.c_b0 = (i64)M * D * W2; g.c_b1 = (i64)D * W2;
+      run_g64(g, N, s);
+    }
+    {  // dq[n] (W1 x D) = sum_m dT[n,m] (W1 x W2) . t2[n,m]^T: K = M segments of W2
+      G64 g = g64(W1, D, W2, top_diff, W2, 1, t12, 1, W2, dq, D);
+      g.nseg = M; g.a_seg = (i64)W1 * W2; g.b_seg = (i64)D * W2;
+      g.a_b0 = (i64)M * W1 * W2; g.b_b0 = (i64)M * D * W2; g.c_b0 = (i64)W1 * D;
+      run_g64(g, N, s);
+    }
+    bil_qw(N, M, W1, D, q, W, tmp, s);
+    {  // da[n] (W2 x D) = sum_m dT[n,m]^T (W2 x W1) . tmp[n,m] (W1 x D): K = M segments of W1
+      G64 g = g64(W2, D, W1, top_diff, 1, W2, tmp, D, 1, da, D);
+      g.nseg = M; g.a_seg = (i64)W1 * W2; g.b_seg = (i64)W1 * D;
+      g.a_b0 = (i64)M * W1 * W2; g.b_b0 = (i64)M * W1 * D; g.c_b0 = (i64)W2 * D;
+      run_g64(g, N, s);
+    }
     if (bias_term && dbias) L(d_dbias, (i64)M * W1 * W2, N, (i64)M * W1 * W2, top_diff, dbias);
   }
   return launch_status();
@@ -364,8 +489,8 @@ int simcross_backward_f64(int mode, int N, int W1, int W2, int D, int M, const d
 int simmatrix_forward_f64(int N, int K1, int K2, const double* q, const double* a, const double* W,
                           double* top, double* scratch, hipStream_t s) {
   if (N == 0) return MMS_OK;
-  L(d_sm_qw, (i64)N * K2, N, K1, K2, q, W, scratch);
-  L(d_sm_top, (i64)N, N, K2, a, scratch, top);
+  run_g64(g64(N, K2, K1, q, K1, 1, W, K2, 1, scratch, K2), 1, s);           // scratch = Q W   (:55-58)
+  hipLaunchKernelGGL(d_sm_top_wave, dim3((unsigned)((N + 3) / 4)), dim3(kT), 0, s, N, K2, a, scratch, top);
   return launch_status();
 }
 
@@ -373,9 +498,21 @@ int simmatrix_backward_f64(int N, int K1, int K2, const double* q, const double*
                            const double* top_diff, int ppd, int pd0, int pd1, double* dq, double* da,
                            double* dW, hipStream_t s) {
   if (N == 0) return MMS_OK;
-  if (ppd && dW) L(d_sm_dw, (i64)K1 * K2, N, K1, K2, q, a, top_diff, dW);
-  if (pd0 && dq) L((d_sm_dx<0>), (i64)N * K1, N, K1, K2, a, W, top_diff, dq);
-  if (pd1 && da) L((d_sm_dx<1>), (i64)N * K2, N, K1, K2, q, W, top_diff, da);
+  if (ppd && dW) {                                   // dW += (diag(dT) Q)^T A   (:75-78, accumulated)
+    G64 g = g64(K1, K2, N, q, 1, K1, a, K2, 1, dW, K2);
+    g.kscale = top_diff; g.beta = 1;
+    run_g64(g, 1, s);
+  }
+  if (pd0 && dq) {                                   // dq = diag(dT) (A W^T)   (:81-86)
+    G64 g = g64(N, K1, K2, a, K2, 1, W, 1, K2, dq, K1);
+    g.rowscale = top_diff;
+    run_g64(g, 1, s);
+  }
+  if (pd1 && da) {                                   // da = diag(dT) (Q W)     (:88-93)
+    G64 g = g64(N, K2, K1, q, K1, 1, W, K2, 1, da, K2);
+    g.rowscale = top_diff;
+    run_g64(g, 1, s);
+  }
   return launch_status();
 }
 

@@ -72,7 +72,9 @@ def test_cosine_f64(shape, oracle, hiplib):
     close(host(da), da_ref, "da")
 
 
-@pytest.mark.parametrize("cfg", [(6, 5, 4, 12, 3, True), (3, 1, 1, 20, 1, False), (2, 7, 7, 9, 4, True)])
+@pytest.mark.parametrize("cfg", [(6, 5, 4, 12, 3, True), (3, 1, 1, 20, 1, False), (2, 7, 7, 9, 4, True),
+                                 (64, 40, 33, 50, 3, True),      # several MFMA tiles, ragged edges; dW on the long-K kernel
+                                 (5, 70, 65, 67, 2, False)])     # more than one 64 x 64 tile per product
 def test_bilinear_f64(cfg, oracle, hiplib):
     N, W1, W2, D, M, bias_term = cfg
     r = np.random.default_rng(11 + sum(cfg[:5]))
@@ -99,9 +101,10 @@ def test_bilinear_f64(cfg, oracle, hiplib):
         assert (bits(host(db)) == bits(db_ref)).all()          # n-ascending column sum: order-defined
 
 
-def test_simmatrix_f64(oracle, hiplib):
+@pytest.mark.parametrize("dims", [(37, 24, 19), (3000, 130, 70)])   # the second: many tiles, dW on the long-K kernel
+def test_simmatrix_f64(dims, oracle, hiplib):
     r = np.random.default_rng(5)
-    N, K1, K2 = 37, 24, 19
+    N, K1, K2 = dims
     q = r.standard_normal((N, K1))
     a = r.standard_normal((N, K2))
     W = r.standard_normal((K1, K2)) * 0.3
