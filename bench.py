@@ -68,6 +68,9 @@ def parse():
                         "split over the ranks (strong scaling); cfg4: 1,517 candidates sharded -> all-gather "
                         "of scores -> MAP/MRR on every rank (strong scaling)")
     p.add_argument("--repeats", type=int, default=REPEATS)
+    p.add_argument("--lead-in", type=int, default=64,
+                   help="untimed steps of the same walk enqueued between each repeat's opening fence and its start "
+                        "event (device busy and at its running clocks when the timed region's first graph arrives)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true")
@@ -250,6 +253,32 @@ class Region:
         main.wait_stream(cap)
         torch.cuda.synchronize()
 
+    def capture_fixed(self, chunks, bi):
+        """Graphs of `chunks` writing bucket `bi`, whatever the running parity (untimed lead-in replays)."""
+        if not self.use_graph:
+            return
+        torch = self.torch
+        main = torch.cuda.current_stream()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(main)
+        with torch.cuda.stream(cap):
+            for (i0, cnt) in chunks:
+                key = (i0 % self.ring, cnt, bi)
+                if key not in self.graphs:
+                    gph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gph, stream=cap):
+                        self.body(i0, cnt, bi)
+                    self.graphs[key] = gph
+        main.wait_stream(cap)
+        torch.cuda.synchronize()
+
+    def run_fixed(self, chunks, bi):
+        for (i0, cnt) in chunks:
+            if self.use_graph:
+                self.graphs[(i0 % self.ring, cnt, bi)].replay()
+            else:
+                self.body(i0, cnt, bi)
+
     def run(self, chunks, before=None, after=None):
         for (i0, cnt) in chunks:
             bi = self.nchunk & 1
@@ -264,9 +293,13 @@ class Region:
                 after(bi)
 
 
-def time_regions(torch, dist, world, main, repeats, run_one):
+def time_regions(torch, dist, world, main, repeats, run_one, pad=None):
     """Time `repeats` regions: barrier + synchronize on both sides of each, HIP events on the launch stream
-    inside the fences; returns the per-repeat milliseconds, MAX over ranks."""
+    inside the fences; returns the per-repeat milliseconds, MAX over ranks.  `pad(r)`, if given, enqueues UNTIMED
+    steps of the same walk (on ring slots other than the region's) between the opening fence and the start
+    event: the device is then busy while the host enqueues the start event and the region's first hipGraph, so a
+    short region (the driver's --steps 20) measures launch-to-launch kernel time like a long one instead of
+    counting the host's submission latency of its one graph (8.3 vs 7.65 us per step without it)."""
     def fence():
         torch.cuda.synchronize()
         if world > 1:
@@ -277,6 +310,8 @@ def time_regions(torch, dist, world, main, repeats, run_one):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fence()
         t0 = time.perf_counter()
+        if pad:
+            pad(r)
         e0.record(main)
         run_one(r)
         e1.record(main)
@@ -321,7 +356,13 @@ def run(args):
     torch.cuda.synchronize()
     warm_chunks = reg.chunks(0, Wm)
     rep_chunks = [reg.chunks(Wm + r * K, K) for r in range(args.repeats)]
+    # untimed lead-in of each repeat: the Gp steps of the walk that PRECEDE the region's first step
+    Gp = max(1, min(G, 32, args.lead_in)) if args.lead_in > 0 else 0
+    pad_reps = (args.lead_in + Gp - 1) // Gp if Gp else 0
+    pad_chunks = [reg.chunks((Wm + r * K - Gp) % ring + ring, Gp) if Gp else [] for r in range(args.repeats)]
     reg.capture([warm_chunks] + rep_chunks)
+    for r in range(args.repeats):
+        reg.capture_fixed(pad_chunks[r], 0)
 
     def gather_bucket(bi):
         """All-gather of the per-pair scores of one bucket (up to GROUP steps x 4096 pairs per rank), on the
@@ -354,7 +395,11 @@ def run(args):
         if world > 1:                                  # the last gathers belong to the region
             main.wait_event(bucket_free[0])
             main.wait_event(bucket_free[1])
-    ev_ms, wall_ms = time_regions(torch, dist, world, main, args.repeats, one)
+    def lead_in(r):
+        for _ in range(pad_reps):
+            reg.run_fixed(pad_chunks[r], 0)       # no gather: nothing reads these scores, and every gather
+                                                  # of an earlier region finished before the fence
+    ev_ms, wall_ms = time_regions(torch, dist, world, main, args.repeats, one, pad=lead_in if Gp else None)
     t_ms = median(ev_ms)
 
     out = None
@@ -388,7 +433,11 @@ def run(args):
                                     "timed steps continue the ring walk" % (ring, ring * 19.7e6 / 2**30),
                        "hip_graph_group": G if use_graph else 0,
                        "clock": "HIP events on the launch stream inside barrier+synchronize fences, max over ranks; "
-                                "median of %d repeats of the %d-step region" % (args.repeats, K),
+                                "median of %d repeats of the %d-step region; %d untimed lead-in steps of the same "
+                                "walk run between each opening fence and its start event (the region's first "
+                                "hipGraph is enqueued while the device is busy and at its running clocks; "
+                                "--lead-in 0 turns it off)" % (args.repeats, K, pad_reps * Gp),
+                       "lead_in_steps_per_repeat": pad_reps * Gp,
                        "repeats_ms_per_step": [x / K for x in ev_ms],
                        "host_wall_ms_per_step_median": median(wall_ms) / K,
                        "ranks_seen": dist.get_world_size() if world > 1 else 1,
@@ -430,6 +479,23 @@ def run(args):
             out["config"]["per_step_gather_variant"] = {
                 "ms_per_step": median(ev1) / K2, "value": world * N_PAIRS * K2 / (median(ev1) * 1e-3),
                 "note": "one all-gather of 4096 scores per rank after every step (16 KiB messages: latency-bound)"}
+
+    # a SHORT region (the driver's --steps 20) carries a fixed cost of two event packets and one graph boundary
+    # (about 9 us: 0.4 us per step at K = 20, nothing at K = 4096); for the record, the same walk over 2048 steps
+    if rank == 0 and world == 1 and K < 1024 and "roofline" in out:
+        K3 = 2048
+        first = Wm + args.repeats * K
+        G3 = max(1, min(args.group, K3))
+        reg3 = Region(torch, step, ring, G3, [torch.empty(G3, N_PAIRS, 1, 1, 1, device="cuda") for _ in range(2)],
+                      use_graph)
+        ch3 = [reg3.chunks(first + r * K3, K3) for r in range(3)]
+        reg3.capture(ch3)
+        ev3, _ = time_regions(torch, dist, world, main, 3, lambda r: reg3.run(ch3[r]), pad=lead_in if Gp else None)
+        us3 = median(ev3) * 1e3 / K3
+        out["roofline"]["long_region"] = {
+            "steps": K3, "us_per_step": us3, "frac": B_UNFUSED / (us3 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "note": "same path, same clock, one region of %d steps (median of 3): what the per-step time is once "
+                    "the two event packets and the graph boundary of a region are amortised" % K3}
 
     # side measurements on rank 0 at N=1 only (not part of the timed region above)
     if rank == 0 and world == 1 and not args.no_variants:
