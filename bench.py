@@ -979,6 +979,13 @@ def other_configs(torch, capi):
         capi.rank_map_mrr(prob, lab, grp)
     out["cfg4_map_mrr_1517_candidates"] = {"us_per_call": (time.perf_counter() - t0) / 20 * 1e6,
                                             "note": "sort + walks + folds + device-to-host copy of the three scalars"}
+    # the same call with its results left on the device (what a Layer's Forward_gpu does), graph-replayed
+    res, eff = torch.empty(2, device="cuda"), torch.empty(1, dtype=torch.int32, device="cuda")
+    try:
+        usd = _graph_time(torch, lambda: capi.rank_map_mrr_device(prob, lab, grp, res, eff, ws=ws))
+        out["cfg4_map_mrr_1517_candidates"]["us_per_call_device_results_graph"] = usd
+    except Exception as ex:                               # a sort that cannot be captured is reported, not hidden
+        out["cfg4_map_mrr_1517_candidates"]["device_results_graph_error"] = str(ex)[:200]
     torch.cuda.empty_cache()
     return out
 

@@ -273,6 +273,15 @@ def rank_map_mrr(prob, label, group, fixed_axis=1, ws=None):
     return o[0], o[1], int(eff.item())
 
 
+def rank_map_mrr_device(prob, label, group, out, eff, fixed_axis=1, ws=None):
+    """The same with the results left on the device: out (2 floats: MAP, MRR), eff (1 int32); no host sync."""
+    n = label.numel()
+    wsp, wsb = (ws or _default_ws).get(lib().mms_rank_workspace_bytes(n), prob.device)
+    check(lib().mms_rank_map_mrr_f32(
+        n, int(fixed_axis), _ptr(prob, "prob"), _ptr(label, "label"), _ptr(group, "group"),
+        out.data_ptr(), out.data_ptr() + 4, eff.data_ptr(), wsp, wsb, _stream()), "mms_rank_map_mrr_f32")
+
+
 def rank_auc(prob, label, fixed_axis=1, ignore_label=None, ws=None):
     n = label.numel()
     wsp, wsb = (ws or _default_ws).get(lib().mms_rank_workspace_bytes(n), prob.device)
