@@ -64,6 +64,73 @@ __global__ __launch_bounds__(kT) void d_cross_fwd(int N, int W1, int W2, int D, 
   }
 }
 
+// Sentence-vector geometry (W1 = W2 = 1), Euclidean: the d-ascending sum is a dependent chain per pair, so a THREAD
+// owns a pair -- but it reads its two rows a 128-byte line at a time (sixteen doubles per operand as eight 16-byte
+// loads, the next tile requested before the current one is summed) instead of one double per round trip:
+// 4096 x 300 forward 69 -> 12 us, same bits (:100-107 order).
+__global__ __launch_bounds__(64) void d_euclid_rows_fwd(int N, int D, const double* __restrict__ q,
+                                                        const double* __restrict__ a, double* __restrict__ top) {
+  const i64 n = (i64)blockIdx.x * 64 + threadIdx.x;
+  if (n >= N) return;
+  const double* x = q + n * D;
+  const double* y = a + n * D;
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  double s = 0;
+  int d = 0;
+  const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  if (vec && D >= 16) {
+    d2 xa[8], ya[8], xb[8], yb[8];
+    auto load = [&](d2 (&xv)[8], d2 (&yv)[8], int at) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        xv[u] = *reinterpret_cast<const d2*>(x + at + 2 * u);
+        yv[u] = *reinterpret_cast<const d2*>(y + at + 2 * u);
+      }
+    };
+    auto sum = [&](const d2 (&xv)[8], const d2 (&yv)[8]) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double f0 = xv[u].x - yv[u].x, f1 = xv[u].y - yv[u].y;
+        s += f0 * f0;
+        s += f1 * f1;
+      }
+    };
+    const int nt = D / 16;                           // whole 128-byte tiles; xa always holds tile t
+    load(xa, ya, 0);
+    int t = 0;
+    for (; t + 2 <= nt; t += 2) {
+      load(xb, yb, 16 * (t + 1));
+      sum(xa, ya);
+      if (t + 2 < nt) load(xa, ya, 16 * (t + 2));
+      sum(xb, yb);
+    }
+    if (t < nt) sum(xa, ya);
+    d = 16 * nt;
+  }
+  for (; d < D; ++d) { const double df = x[d] - y[d]; s += df * df; }
+  top[n] = 1 / (1 + sqrt(s));
+}
+
+// Sentence-vector geometry, cosine (dot and norms are BLAS-ordered in the reference: any order, 1e-12): one WAVE
+// per pair, lanes stride over d, three wave sums.
+__global__ __launch_bounds__(kT) void d_cosine_rows_fwd(int N, int D, const double* __restrict__ q,
+                                                        const double* __restrict__ a, double* __restrict__ n0,
+                                                        double* __restrict__ n1, double* __restrict__ top) {
+  const i64 n = (i64)blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int lane = threadIdx.x & 63;
+  const double* x = q + n * D;
+  const double* y = a + n * D;
+  double sxx = 0, syy = 0, sxy = 0;
+  for (int d = lane; d < D; d += 64) { const double u = x[d], v = y[d]; sxx += u * u; syy += v * v; sxy += u * v; }
+  for (int o = 32; o; o >>= 1) { sxx += __shfl_xor(sxx, o); syy += __shfl_xor(syy, o); sxy += __shfl_xor(sxy, o); }
+  if (lane == 0) {
+    const double a0 = sqrt(sxx), a1 = sqrt(syy);
+    n0[n] = a0; n1[n] = a1;
+    top[n] = sxy / a0 / a1;                                                           // :135
+  }
+}
+
 // dq[n,j,d] = sum_k tt (k ascending); SIDE = 1: da[n,k,d] = sum_j (-tt or the cosine term), j ascending
 template <int MODE, int SIDE>
 __global__ __launch_bounds__(kT) void d_cross_bwd(int N, int W1, int W2, int D, const double* __restrict__ q,
@@ -402,8 +469,13 @@ int simcross_forward_f64(int mode, int N, int W1, int W2, int D, int M, const do
                          const double* W, const double* bias, double* top, double* norm0, double* norm1,
                          void* ws, size_t ws_bytes, hipStream_t s) {
   if (N == 0) return MMS_OK;
-  if (mode == 1) {
+  const bool rows = (W1 == 1 && W2 == 1);
+  if (mode == 1 && rows) {
+    hipLaunchKernelGGL(d_euclid_rows_fwd, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s, N, D, q, a, top);
+  } else if (mode == 1) {
     L((d_cross_fwd<1>), (i64)N * W1 * W2, N, W1, W2, D, q, a, nullptr, nullptr, top);
+  } else if (mode == 0 && rows) {
+    hipLaunchKernelGGL(d_cosine_rows_fwd, dim3((unsigned)((N + 3) / 4)), dim3(kT), 0, s, N, D, q, a, norm0, norm1, top);
   } else if (mode == 0) {
     L(d_row_norm, (i64)N * W1, q, norm0, (i64)N * W1, D);
     L(d_row_norm, (i64)N * W2, a, norm1, (i64)N * W2, D);

@@ -32,7 +32,8 @@ def nanlike(shape):
     return torch.full(shape, float("nan"), dtype=torch.float64, device="cuda")
 
 
-@pytest.mark.parametrize("shape", [(64, 1, 1, 300), (5, 3, 4, 7), (2, 40, 40, 50), (1, 1, 1, 1)])
+@pytest.mark.parametrize("shape", [(64, 1, 1, 300), (5, 3, 4, 7), (2, 40, 40, 50), (1, 1, 1, 1),
+                                   (67, 1, 1, 301), (5, 1, 1, 15), (9, 1, 1, 48), (130, 1, 1, 1024)])   # tiled rows kernel: odd D (rows of alternating alignment), no whole tile, whole tiles only
 def test_euclid_f64_bitexact(shape, oracle, hiplib):
     N, W1, W2, D = shape
     r = np.random.default_rng(sum(shape))
@@ -52,7 +53,7 @@ def test_euclid_f64_bitexact(shape, oracle, hiplib):
     assert (host(dq) == 0).all() and (host(da) == 0).all()
 
 
-@pytest.mark.parametrize("shape", [(33, 1, 1, 300), (4, 5, 3, 16)])
+@pytest.mark.parametrize("shape", [(33, 1, 1, 300), (4, 5, 3, 16), (70, 1, 1, 37)])
 def test_cosine_f64(shape, oracle, hiplib):
     N, W1, W2, D = shape
     r = np.random.default_rng(7 + sum(shape))
