@@ -332,29 +332,32 @@ size_t mms_embed_workspace_bytes(int M, int N);
 
 /* Embed fused into SimCross's loads (forward / scoring; dist_mode 0 or 1):
  *   top == SimCross(Embed(index_q), Embed(index_a))
- * i.e. embed_layer.cpp:135-152 (bias_term false, as the driver's embedding layers are,
- * examples/trec_qa_w2v_mms/do_trec_qa_clean.py:462) followed by sim_cross_layer.cpp:96-139,
- * without the (N,W,D) blobs in between.  index_q (N,W1) and index_a (N,W2) hold word ids as
- * floats, clamped into [0,K) like mms_embed_forward_f32; weight (K,D); top (N,1,W1,W2);
- * norm0 (N,W1) / norm1 (N,W2) receive the row norms in dist_mode 0 (NULL otherwise).  Results
- * are the bits of the two separate calls (Euclid: the reference's CPU bits).  dist_mode 2 has
- * its own entry point below (it needs W and bias). */
+ * i.e. embed_layer.cpp:135-152 followed by sim_cross_layer.cpp:96-139, without the (N,W,D) blobs in
+ * between.  index_q (N,W1) and index_a (N,W2) hold word ids as floats, clamped into [0,K) like
+ * mms_embed_forward_f32; weight (K,D) is the table BOTH Embed layers read (the driver shares it by
+ * parameter name, do_trec_qa_clean.py:462-467); embed_bias (D) is their shared bias blob or NULL
+ * (bias_term false) -- the driver's Embed layers DO carry one (`bias_term` is left at its default,
+ * the `#bias_term=False` of :462 is commented out), so a row is bias[d] + weight[id][d], one
+ * rounding, as the layer's gemm gives it (:146-151); top (N,1,W1,W2); norm0 (N,W1) / norm1 (N,W2)
+ * receive the row norms in dist_mode 0 (NULL otherwise).  Results are the bits of the two separate
+ * calls (Euclid: the reference's CPU bits).  dist_mode 2 has its own entry point below (it needs
+ * W and bias). */
 int mms_embed_simcross_forward_f32(int dist_mode, int N, int W1, int W2, int D, int K,
                                    const float* index_q, const float* index_a,
-                                   const float* weight, float* top, float* norm0,
-                                   float* norm1, void* stream);
+                                   const float* weight, const float* embed_bias, float* top,
+                                   float* norm0, float* norm1, void* stream);
 
 /* The same fusion for dist_mode 2, the mode network_v4 scores with (do_trec_qa_clean.py:468):
  *   top (N,M,W1,W2) == SimCross_bilinear(Embed(index_q), Embed(index_a); W (M,D,D), bias (M,W1,W2) or NULL)
- * embed_layer.cpp:135-152 (bias_term false) followed by sim_cross_layer.cpp:140-161, ONE launch: the word-grid
+ * embed_layer.cpp:135-152 (embed_bias as above) followed by sim_cross_layer.cpp:140-161, ONE launch: the word-grid
  * forward kernels gather their q / a images from the table themselves.  Same kernels and operand values as
  * mms_embed_forward_f32 x2 + mms_simcross_forward_f32, hence the same bits (1e-5 vs the reference: BLAS order).
  * Covers the word-grid geometries of the fused forward (W1, W2 <= 48, D <= 64, and either N >= 512 or
  * N <= 256 with N*M <= 65535); anything else returns MMS_ERR_UNSUPPORTED -- run the two layers separately. */
 int mms_embed_simcross_bilinear_forward_f32(int N, int W1, int W2, int D, int M, int K,
                                             const float* index_q, const float* index_a,
-                                            const float* weight, const float* W, const float* bias,
-                                            float* top, void* stream);
+                                            const float* weight, const float* embed_bias,
+                                            const float* W, const float* bias, float* top, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Batch feed: dst[i,:] = src[perm[first+i],:], i < rows,

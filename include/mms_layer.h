@@ -76,6 +76,13 @@ int mms_layer_set_option(mms_layer_t* l, const char* key, int value);
 typedef struct mms_net mms_net_t;
 mms_net_t* mms_net_create(const char* prototxt, int phase, char* err, int err_len);
 void mms_net_destroy(mms_net_t* n);
+/* "fuse_embed_scoring" = 1 (forward-only use: evaluation): a SimCross layer fed by two Embed layers that read one
+ * table (and bias) shared by parameter name, and feed nothing else, is run straight from the word ids -- one
+ * launch, the (N,W,D) blobs never written; geometries without a fused kernel run the three layers as usual;
+ * mms_net_backward after such a Forward aborts.  Returns 0 if the option is known.  mms_net_num_fused: how many
+ * SimCross layers the current plan runs that way (after mms_net_setup). */
+int mms_net_set_option(mms_net_t* n, const char* key, int value);
+int mms_net_num_fused(const mms_net_t* n);
 const char* mms_net_name(const mms_net_t* n);
 int mms_net_num_layers(const mms_net_t* n);
 const char* mms_net_layer_name(const mms_net_t* n, int i);

@@ -26,8 +26,8 @@ _SIGNATURES = {
     "mms_simcross_backward_f32": (_i, [_i] * 6 + [_vp] * 3 + [_i] + [_vp] * 4 + [_i, _i] + [_vp] * 5 + [_sz, _vp]),
     "mms_simcross_forward_backward_f32": (_i, [_i] * 6 + [_vp] * 13 + [_sz, _vp]),
     "mms_simmatrix_workspace_bytes": (_sz, [_i] * 3),
-    "mms_embed_simcross_forward_f32": (_i, [_i] * 6 + [_vp] * 7),
-    "mms_embed_simcross_bilinear_forward_f32": (_i, [_i] * 6 + [_vp] * 7),
+    "mms_embed_simcross_forward_f32": (_i, [_i] * 6 + [_vp] * 8),
+    "mms_embed_simcross_bilinear_forward_f32": (_i, [_i] * 6 + [_vp] * 8),
     "mms_simmatrix_forward_f32": (_i, [_i] * 3 + [_vp] * 6),
     "mms_simmatrix_backward_f32": (_i, [_i] * 3 + [_vp] * 4 + [_i] * 3 + [_vp] * 4 + [_sz, _vp]),
     "mms_simmatrix_backward_cached_f32": (_i, [_i] * 3 + [_vp] * 5 + [_i] * 3 + [_vp] * 4 + [_sz, _vp]),
@@ -182,18 +182,19 @@ def simcross_forward_backward(mode, q, a, top_diff, top, dq, da, W=None, bias=No
         "mms_simcross_forward_backward_f32")
 
 
-def embed_simcross_forward(mode, index_q, index_a, weight, top, norm0=None, norm1=None):
-    """top = SimCross(Embed(index_q), Embed(index_a)), dist_mode 0 / 1, the gather fused into the loads."""
+def embed_simcross_forward(mode, index_q, index_a, weight, top, norm0=None, norm1=None, embed_bias=None):
+    """top = SimCross(Embed(index_q), Embed(index_a)), dist_mode 0 / 1, the gather fused into the loads;
+    embed_bias (D) = the Embed layers' bias blob, if they have one."""
     N, W1 = index_q.shape[0], index_q.shape[1]
     W2 = index_a.shape[1]
     K, D = weight.shape
     check(lib().mms_embed_simcross_forward_f32(
         mode, N, W1, W2, D, K, _ptr(index_q, "index_q"), _ptr(index_a, "index_a"), _ptr(weight, "weight"),
-        _ptr(top, "top"), _ptr(norm0, "norm0", True), _ptr(norm1, "norm1", True), _stream()),
-        "mms_embed_simcross_forward_f32")
+        _ptr(embed_bias, "embed_bias", True), _ptr(top, "top"), _ptr(norm0, "norm0", True),
+        _ptr(norm1, "norm1", True), _stream()), "mms_embed_simcross_forward_f32")
 
 
-def embed_simcross_bilinear_forward(index_q, index_a, weight, W, bias, top):
+def embed_simcross_bilinear_forward(index_q, index_a, weight, W, bias, top, embed_bias=None):
     """top (N,M,W1,W2) = SimCross dist_mode 2 of (Embed(index_q), Embed(index_a)), one launch (word grids)."""
     N, W1 = index_q.shape[0], index_q.shape[1]
     W2 = index_a.shape[1]
@@ -201,7 +202,7 @@ def embed_simcross_bilinear_forward(index_q, index_a, weight, W, bias, top):
     M = W.shape[0]
     check(lib().mms_embed_simcross_bilinear_forward_f32(
         N, W1, W2, D, M, K, _ptr(index_q, "index_q"), _ptr(index_a, "index_a"), _ptr(weight, "weight"),
-        _ptr(W, "W"), _ptr(bias, "bias", True), _ptr(top, "top"), _stream()),
+        _ptr(embed_bias, "embed_bias", True), _ptr(W, "W"), _ptr(bias, "bias", True), _ptr(top, "top"), _stream()),
         "mms_embed_simcross_bilinear_forward_f32")
 
 

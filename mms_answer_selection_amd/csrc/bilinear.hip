@@ -792,6 +792,7 @@ struct PairGather {
   const float* iq;
   const float* ia;
   int K;
+  const float* bias;     // the Embed layer's bias (D floats) or nullptr: row value = bias[d] + table[id][d]
 };
 __device__ __forceinline__ int pair_gather_id(float v, int K) {   // as mms_embed_forward_f32 clamps
   const int i = (int)v;
@@ -802,7 +803,7 @@ template <int KS>                                  // k steps of 4: 13 covers D 
 __global__ __launch_bounds__(256) void bilinear_pair_fwd_kernel(
     int N, int W1, int W2, int D, int M, const float* __restrict__ q, const float* __restrict__ a,
     const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ top,
-    PairGather g = PairGather{nullptr, nullptr, 0}) {
+    PairGather g = PairGather{nullptr, nullptr, 0, nullptr}) {
   __shared__ float qs[PF_ROWS * PF_LS];
   __shared__ float as[PF_ROWS * PF_LS];
   __shared__ float ts[4][16 * PF_LS];
@@ -855,6 +856,7 @@ __global__ __launch_bounds__(256) void bilinear_pair_fwd_kernel(
       const int c = e - (e / PF_LS) * PF_LS;
       vq[u] = q[(size_t)pair_gather_id(fq[u], g.K) * D + min(c, D - 1)];
       va[u] = a[(size_t)pair_gather_id(fa[u], g.K) * D + min(c, D - 1)];
+      if (g.bias) { const float bv = g.bias[min(c, D - 1)]; vq[u] = bv + vq[u]; va[u] = bv + va[u]; }
     }
   } else {
 #pragma unroll
@@ -1081,7 +1083,7 @@ template <int KSD>
 __global__ __launch_bounds__(512) void bilinear_pairm_fwd_kernel(
     int N, int W1, int W2, int D, int M, const float* __restrict__ q, const float* __restrict__ a,
     const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ top,
-    PairGather gth = PairGather{nullptr, nullptr, 0}) {
+    PairGather gth = PairGather{nullptr, nullptr, 0, nullptr}) {
   __shared__ float qs[FB_W * FB_LS], as[FB_W * FB_LS], ws[FB_D * FB_LS], ps[FB_W * FB_LS];
   constexpr int NT = 512, NWV = NT / 64;
   const int n = blockIdx.x / M, m = blockIdx.x - n * M;
@@ -1105,6 +1107,7 @@ __global__ __launch_bounds__(512) void bilinear_pairm_fwd_kernel(
         const int e = NT * u + t, c = e - (e / FB_LS) * FB_LS;
         vq[u] = q[(size_t)pair_gather_id(fq[u], gth.K) * D + min(c, D - 1)];
         va[u] = a[(size_t)pair_gather_id(fa[u], gth.K) * D + min(c, D - 1)];
+        if (gth.bias) { const float bv = gth.bias[min(c, D - 1)]; vq[u] = bv + vq[u]; va[u] = bv + va[u]; }
       }
     } else {
 #pragma unroll
@@ -1182,10 +1185,10 @@ static bool pair_bwd_eligible(int N, int W1, int W2, int D, int M) {
 // sim_cross_layer.cpp:140-161, the gather done by the staging loads.  Same kernels, same operand values: the
 // bits of mms_embed_forward_f32 x2 followed by mms_simcross_forward_f32.  Other geometries: MMS_ERR_UNSUPPORTED.
 int embed_bilinear_forward(int N, int W1, int W2, int D, int M, int K, const float* index_q,
-                           const float* index_a, const float* table, const float* W, const float* bias,
-                           float* top, hipStream_t s) {
+                           const float* index_a, const float* table, const float* embed_bias, const float* W,
+                           const float* bias, float* top, hipStream_t s) {
   if (N == 0) return MMS_OK;
-  const PairGather g{index_q, index_a, K};
+  const PairGather g{index_q, index_a, K, embed_bias};
   if (W1 <= PF_ROWS && W2 <= PF_ROWS && D <= 16 * PF_TD && W1 * W2 > 1 && N >= 512) {
     if (D <= 52)
       hipLaunchKernelGGL(bilinear_pair_fwd_kernel<13>, dim3(N), dim3(256), 0, s, N, W1, W2, D, M, table, table, W,

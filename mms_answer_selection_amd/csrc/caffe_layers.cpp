@@ -10,6 +10,7 @@
 // and a silent host fallback would void every parity claim.
 #include <map>
 #include <set>
+#include <type_traits>
 #include "caffe_api.hpp"
 
 #include <cctype>
@@ -226,6 +227,39 @@ class SimCrossLayer : public Layer<Dtype> {
     if (key != "euclid_backward_mode" || value < -1 || value > 1) return false;
     euclid_bwd_mode_ = value;
     return true;
+  }
+
+  // Scoring straight from word ids (PathNet's "fuse_embed_scoring"): top = this layer applied to
+  // (Embed(ids_q), Embed(ids_a)) with the Embed layers' shared table and bias, the gather done by the forward
+  // kernels' own loads (include/mms.h: mms_embed_simcross_forward_f32 / _bilinear_forward_f32).  `bottom` are the
+  // layer's ordinary bottoms -- shapes only, their data is neither read nor written.  Returns false when the
+  // geometry has no fused kernel (the caller then runs the Embed layers and Forward as usual).
+  bool ForwardFromWordIds(const Blob<Dtype>& ids_q, const Blob<Dtype>& ids_a, const Blob<Dtype>& table,
+                          const Blob<Dtype>* embed_bias, const vector<Blob<Dtype>*>& bottom,
+                          const vector<Blob<Dtype>*>& top) {
+    if constexpr (std::is_same<Dtype, float>::value) {
+      this->Reshape(bottom, top);
+      const int N = bottom[0]->num(), W1 = bottom[0]->channels(), W2 = bottom[1]->channels(), D = bottom[0]->height();
+      if (ids_q.count() != N * W1 || ids_a.count() != N * W2 || table.num_axes() != 2 || table.shape(1) != D) return false;
+      const int K = table.shape(0), M = top[0]->channels();
+      const float* eb = embed_bias ? embed_bias->gpu_data() : nullptr;
+      int rc;
+      if (dist_mode_ == 2)
+        rc = mms_embed_simcross_bilinear_forward_f32(N, W1, W2, D, M, K, ids_q.gpu_data(), ids_a.gpu_data(),
+                                                     table.gpu_data(), eb, this->blobs_[0]->gpu_data(),
+                                                     this->blobs_.size() > 1 ? this->blobs_[1]->gpu_data() : nullptr,
+                                                     top[0]->mutable_gpu_data(), nullptr);
+      else
+        rc = mms_embed_simcross_forward_f32(dist_mode_, N, W1, W2, D, K, ids_q.gpu_data(), ids_a.gpu_data(),
+                                            table.gpu_data(), eb, top[0]->mutable_gpu_data(),
+                                            dist_mode_ == 0 ? data0_norm_.mutable_gpu_data() : nullptr,
+                                            dist_mode_ == 0 ? data1_norm_.mutable_gpu_data() : nullptr, nullptr);
+      if (rc == MMS_ERR_UNSUPPORTED) return false;
+      mms_check(rc, "mms_embed_simcross_forward");
+      return true;
+    } else {
+      return false;                                    // the fused entry points are fp32
+    }
   }
 
  protected:
@@ -1262,14 +1296,44 @@ class PathNet {
       L.runnable = true;
       ++n;
     }
+    plan_fusion();
     return n;
   }
+  // "fuse_embed_scoring" (forward-only nets: evaluation, do_trec_qa_clean.py:617-650): a SimCross layer whose two
+  // bottoms come from Embed layers that read ONE table (shared by parameter name, as network_v4's do) and feed
+  // nothing else is run straight from the word ids -- the (N, W, D) blobs are never written.
+  bool SetOption(const string& key, int value) {
+    if (key != "fuse_embed_scoring") return false;
+    fuse_embed_ = value != 0;
+    plan_fusion();
+    return true;
+  }
+  int num_fused() const { return (int)fused_.size(); }
   float Forward() {
     float loss = 0;
-    for (PathNetLayer& L : layers_) if (L.runnable) loss += L.layer->Forward(L.bottom, L.top);
+    for (size_t i = 0; i < layers_.size(); ++i) {
+      PathNetLayer& L = layers_[i];
+      if (!L.runnable || skipped_.count(i)) continue;
+      auto f = fused_.find(i);
+      if (f != fused_.end()) {
+        PathNetLayer& Eq = layers_[f->second.first];
+        PathNetLayer& Ea = layers_[f->second.second];
+        auto* sim = static_cast<SimCrossLayer<float>*>(L.layer.get());
+        auto& eb = Eq.layer->blobs();
+        if (sim->ForwardFromWordIds(*Eq.bottom[0], *Ea.bottom[0], *eb[0], eb.size() > 1 ? eb[1].get() : nullptr,
+                                    L.bottom, L.top))
+          continue;
+        Eq.layer->Forward(Eq.bottom, Eq.top);            // no fused kernel for this geometry: the usual three
+        Ea.layer->Forward(Ea.bottom, Ea.top);
+      }
+      loss += L.layer->Forward(L.bottom, L.top);
+    }
+    ran_fused_ = !fused_.empty();
     return loss;
   }
   void Backward() {
+    CHECK(!ran_fused_) << "Backward on a net whose last Forward scored from word ids (fuse_embed_scoring): the "
+                          "Embed tops were never written";
     for (size_t i = layers_.size(); i-- > 0;) {
       PathNetLayer& L = layers_[i];
       if (!L.runnable) continue;
@@ -1322,8 +1386,42 @@ class PathNet {
       blobs[i] = it->second;                                         // ShareData + ShareDiff with the owner
     }
   }
+  void plan_fusion() {
+    fused_.clear();
+    skipped_.clear();
+    if (!fuse_embed_) return;
+    auto producer = [&](size_t before, Blob<float>* b) -> int {
+      for (size_t i = before; i-- > 0;)
+        for (Blob<float>* t : layers_[i].top) if (t == b) return (int)i;
+      return -1;
+    };
+    auto consumers = [&](Blob<float>* b) {
+      int c = 0;
+      for (const PathNetLayer& L : layers_) for (Blob<float>* x : L.bottom) if (x == b) ++c;
+      return c;
+    };
+    for (size_t i = 0; i < layers_.size(); ++i) {
+      PathNetLayer& L = layers_[i];
+      if (!L.runnable || L.param.type() != "SimCross" || L.bottom.size() != 2) continue;
+      const int eq = producer(i, L.bottom[0]), ea = producer(i, L.bottom[1]);
+      if (eq < 0 || ea < 0 || eq == ea) continue;
+      const PathNetLayer &Eq = layers_[eq], &Ea = layers_[ea];
+      if (!Eq.runnable || !Ea.runnable || Eq.param.type() != "Embed" || Ea.param.type() != "Embed") continue;
+      if (Eq.top.size() != 1 || Ea.top.size() != 1 || Eq.bottom.size() != 1 || Ea.bottom.size() != 1) continue;
+      if (consumers(L.bottom[0]) != 1 || consumers(L.bottom[1]) != 1) continue;        // someone else reads q or a
+      auto &bq = Eq.layer->blobs(), &ba = Ea.layer->blobs();
+      if (bq.empty() || bq.size() != ba.size() || bq[0].get() != ba[0].get()) continue;  // two tables
+      if (bq.size() > 1 && bq[1].get() != ba[1].get()) continue;                          // two biases
+      fused_[i] = std::make_pair((size_t)eq, (size_t)ea);
+      skipped_.insert((size_t)eq);
+      skipped_.insert((size_t)ea);
+    }
+  }
   string name_;
   int phase_;
+  bool fuse_embed_ = false, ran_fused_ = false;
+  std::map<size_t, std::pair<size_t, size_t> > fused_;   // SimCross layer -> its two Embed producers
+  std::set<size_t> skipped_;
   vector<PathNetLayer> layers_;
   std::map<string, Blob<float>*> blobs_;
   vector<string> blob_order_;
@@ -1429,6 +1527,8 @@ mms_net_t* mms_net_create(const char* prototxt, int phase, char* err, int err_le
   return h;
 }
 void mms_net_destroy(mms_net_t* n) { delete n; }
+int mms_net_set_option(mms_net_t* n, const char* key, int value) { return (key && n->net->SetOption(key, value)) ? 0 : 1; }
+int mms_net_num_fused(const mms_net_t* n) { return n->net->num_fused(); }
 const char* mms_net_name(const mms_net_t* n) { return n->net->name().c_str(); }
 int mms_net_num_layers(const mms_net_t* n) { return (int)n->net->layers().size(); }
 const char* mms_net_layer_name(const mms_net_t* n, int i) { return n->net->layers()[i].param.name().c_str(); }

@@ -26,14 +26,14 @@ int bilinear_backward(int N, int W1, int W2, int D, int M, const float* q, const
                       const float* W, int bias_term, const float* top_diff, float* dq, float* da,
                       float* dW, float* dbias, void* ws, size_t ws_bytes, hipStream_t s);
 int embed_bilinear_forward(int N, int W1, int W2, int D, int M, int K, const float* index_q,
-                           const float* index_a, const float* table, const float* W, const float* bias,
-                           float* top, hipStream_t s);
+                           const float* index_a, const float* table, const float* embed_bias, const float* W,
+                           const float* bias, float* top, hipStream_t s);
 size_t simmatrix_workspace_bytes(int N, int K1, int K2);
 int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, const float* W,
                       float* top, float* qw, hipStream_t s);
 int embed_simcross_forward(int mode, int N, int W1, int W2, int D, int K, const float* index_q,
-                           const float* index_a, const float* weight, float* top, float* norm0,
-                           float* norm1, hipStream_t s);
+                           const float* index_a, const float* weight, const float* embed_bias, float* top,
+                           float* norm0, float* norm1, hipStream_t s);
 int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, const float* W,
                        const float* top_diff, int ppd, int pd0, int pd1, float* dq, float* da,
                        float* dW, const float* qw, void* ws, size_t ws_bytes, hipStream_t s);
@@ -240,24 +240,26 @@ int mms_simcross_euclid_forward_backward_f16(int N, int D, const void* q_f16, co
 
 int mms_embed_simcross_forward_f32(int dist_mode, int N, int W1, int W2, int D, int K,
                                    const float* index_q, const float* index_a, const float* weight,
-                                   float* top, float* norm0, float* norm1, void* stream) {
+                                   const float* embed_bias, float* top, float* norm0, float* norm1, void* stream) {
   if (dist_mode != 0 && dist_mode != 1) return MMS_ERR_UNSUPPORTED;   // bilinear: run Embed, then SimCross
   if (!dims_ok(dist_mode, N, W1, W2, D, 1) || K <= 0 || (long long)K * D > 0x7fffffffLL)
     return MMS_ERR_INVALID_ARG;
   if (N == 0) return MMS_OK;
   if (!index_q || !index_a || !weight || !top) return MMS_ERR_INVALID_ARG;
   if (dist_mode == 0 && (!norm0 || !norm1)) return MMS_ERR_INVALID_ARG;
-  return embed_simcross_forward(dist_mode, N, W1, W2, D, K, index_q, index_a, weight, top, norm0, norm1,
-                                as_stream(stream));
+  return embed_simcross_forward(dist_mode, N, W1, W2, D, K, index_q, index_a, weight, embed_bias, top, norm0,
+                                norm1, as_stream(stream));
 }
 
 int mms_embed_simcross_bilinear_forward_f32(int N, int W1, int W2, int D, int M, int K,
                                             const float* index_q, const float* index_a, const float* weight,
-                                            const float* W, const float* bias, float* top, void* stream) {
+                                            const float* embed_bias, const float* W, const float* bias,
+                                            float* top, void* stream) {
   if (!dims_ok(2, N, W1, W2, D, M) || K <= 0 || (long long)K * D > 0x7fffffffLL) return MMS_ERR_INVALID_ARG;
   if (N == 0) return MMS_OK;
   if (!index_q || !index_a || !weight || !W || !top) return MMS_ERR_INVALID_ARG;
-  return embed_bilinear_forward(N, W1, W2, D, M, K, index_q, index_a, weight, W, bias, top, as_stream(stream));
+  return embed_bilinear_forward(N, W1, W2, D, M, K, index_q, index_a, weight, embed_bias, W, bias, top,
+                                as_stream(stream));
 }
 
 size_t mms_simmatrix_workspace_bytes(int N, int K1, int K2) {

@@ -985,13 +985,14 @@ __device__ __forceinline__ int gather_id(float v, int K) {
 __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ x,
                                                        float* __restrict__ nrm,
                                                        long long rows, int D,
-                                                       const float* __restrict__ index, int K) {
+                                                       const float* __restrict__ index, int K,
+                                                       const float* __restrict__ ebias = nullptr) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* r = x + (index ? (long long)gather_id(index[row], K) : row) * D;
   float s = 0.f;
-  for (int i = lane; i < D; i += 64) s += r[i] * r[i];
+  for (int i = lane; i < D; i += 64) { const float v = ebias ? ebias[i] + r[i] : r[i]; s += v * v; }
   s = wave_sum(s);
   if (lane == 0) nrm[row] = sqrtf(s);
 }
@@ -1110,6 +1111,8 @@ struct CrossGather {
   const float* iq;
   const float* ia;
   int K;
+  const float* bias;     // the Embed layer's bias (D floats) or nullptr: row value = bias[d] + table[id][d], the
+                         // one rounding of embed_layer.cpp:146-151 (gemm with alpha = beta = 1)
 };
 
 // Generic staging: q/a are staged DC floats of d at a time in LDS with stride DC+1 (bank =
@@ -1162,6 +1165,13 @@ __global__ __launch_bounds__(256) void cross_fwd_kernel(
       for (int r = 0; r < TJ; r += 2) rq[r / 2] = q[(size_t)rowoff[wave][r + lrow] + col];
 #pragma unroll
       for (int r = 0; r < TK; r += 2) ra[r / 2] = a[(size_t)rowoff[wave][TJ + r + lrow] + col];
+      if (gt.bias) {
+        const float bv = gt.bias[col];
+#pragma unroll
+        for (int r = 0; r < TJ; r += 2) rq[r / 2] = bv + rq[r / 2];
+#pragma unroll
+        for (int r = 0; r < TK; r += 2) ra[r / 2] = bv + ra[r / 2];
+      }
       return;
     }
 #pragma unroll
@@ -1239,6 +1249,16 @@ __global__ __launch_bounds__(128) void cross_fwd_image_kernel(
         const int e = e0 + 64 * u + lane;
         rq[u] = t2[(size_t)gather_id(idq[u], gt.K) * R2 + min(e, NQ2 - 1) % R2];
         ra[u] = t2[(size_t)gather_id(ida[u], gt.K) * R2 + min(e, NA2 - 1) % R2];
+      }
+      if (gt.bias) {
+        const float2* b2 = reinterpret_cast<const float2*>(gt.bias);   // D even: the row pitch makes this 8-byte aligned with the table
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + 64 * u + lane;
+          const float2 bq = b2[min(e, NQ2 - 1) % R2], ba = b2[min(e, NA2 - 1) % R2];
+          rq[u].x = bq.x + rq[u].x; rq[u].y = bq.y + rq[u].y;
+          ra[u].x = ba.x + ra[u].x; ra[u].y = ba.y + ra[u].y;
+        }
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -1645,7 +1665,7 @@ static bool cross_bwd_lane_ok(bool exact, int N, int W1, int W2, int D) {
 template <int MODE>
 static void launch_cross_fwd(const float* q, const float* a, const float* n0,
                              const float* n1, float* top, int N, int W1, int W2,
-                             int D, hipStream_t s, CrossGather gt = CrossGather{nullptr, nullptr, 0}) {
+                             int D, hipStream_t s, CrossGather gt = CrossGather{nullptr, nullptr, 0, nullptr}) {
   // Register tile per lane: as large as possible (fewer LDS reads per flop) while the
   // launch still has enough waves to occupy the chip (small N: smaller tiles, more waves).
   auto r_cap = [](int w, int cap) { int r = (w + 7) / 8; return r > cap ? cap : r; };
@@ -1865,16 +1885,16 @@ int simcross_elementwise_forward(int mode, int N, int W1, int W2, int D,
 // embedding layers have bias_term false, do_trec_qa_clean.py:462): embed_layer.cpp:135-152 followed by
 // sim_cross_layer.cpp:96-139, with the gather done by SimCross's own loads.
 int embed_simcross_forward(int mode, int N, int W1, int W2, int D, int K, const float* index_q,
-                           const float* index_a, const float* weight, float* top, float* norm0,
-                           float* norm1, hipStream_t s) {
+                           const float* index_a, const float* weight, const float* embed_bias, float* top,
+                           float* norm0, float* norm1, hipStream_t s) {
   if (N == 0) return MMS_OK;
-  const CrossGather gt{index_q, index_a, K};
+  const CrossGather gt{index_q, index_a, K, embed_bias};
   if (mode == 1) {
     launch_cross_fwd<1>(weight, weight, nullptr, nullptr, top, N, W1, W2, D, s, gt);
   } else {
     const long long r0 = (long long)N * W1, r1 = (long long)N * W2;
-    hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)((r0 + 3) / 4)), dim3(256), 0, s, weight, norm0, r0, D, index_q, K);
-    hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)((r1 + 3) / 4)), dim3(256), 0, s, weight, norm1, r1, D, index_a, K);
+    hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)((r0 + 3) / 4)), dim3(256), 0, s, weight, norm0, r0, D, index_q, K, embed_bias);
+    hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)((r1 + 3) / 4)), dim3(256), 0, s, weight, norm1, r1, D, index_a, K, embed_bias);
     launch_cross_fwd<0>(weight, weight, norm0, norm1, top, N, W1, W2, D, s, gt);
   }
   return launch_status();

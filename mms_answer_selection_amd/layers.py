@@ -45,6 +45,8 @@ _SIGNATURES = {
     "mms_layer_set_option": (_i, [_vp, C.c_char_p, _i]),
     "mms_net_create": (_vp, [C.c_char_p, _i, C.c_char_p, _i]),
     "mms_net_destroy": (None, [_vp]),
+    "mms_net_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "mms_net_num_fused": (_i, [_vp]),
     "mms_net_name": (C.c_char_p, [_vp]),
     "mms_net_num_layers": (_i, [_vp]),
     "mms_net_layer_name": (C.c_char_p, [_vp, _i]),
@@ -311,6 +313,16 @@ class Net:
 
     def SetUp(self):
         return lib().mms_net_setup(self._h)
+
+    def set_option(self, key, value):
+        """'fuse_embed_scoring': score straight from word ids where a SimCross layer is fed by two Embed layers
+        sharing one table (forward-only use; include/mms_layer.h: mms_net_set_option)."""
+        if lib().mms_net_set_option(self._h, key.encode(), int(value)):
+            raise KeyError(key)
+
+    @property
+    def num_fused(self):
+        return lib().mms_net_num_fused(self._h)
 
     def Forward(self):
         return float(lib().mms_net_forward(self._h))

@@ -72,6 +72,18 @@ def test_embed_fused_into_simcross_forward(cfg, oracle, hiplib):
     capi.embed_simcross_forward(0, dev(iq), dev(ia), dev(weight), ctop, norm0=n0, norm1=n1)
     assert_close(ctop.cpu().numpy(), ctop_ref, TOL, "cosine scores of the fused call")
     assert_close(n0.cpu().numpy(), n0_ref, TOL, "norm0")
+    # with the Embed layers' bias (the driver's layers have one): row = bias + table[id], one rounding
+    eb = r.uniform(-0.3, 0.3, D).astype(np.float32)
+    qb = oracle.embed_forward(iq.reshape(-1), weight, eb).reshape(N, W1, D)
+    ab = oracle.embed_forward(ia.reshape(-1), weight, eb).reshape(N, W2, D)
+    topb_ref, _, _ = oracle.simcross_forward(1, qb, ab)
+    topb = torch.full(top_ref.shape, float("nan"), device="cuda")
+    capi.embed_simcross_forward(1, dev(iq), dev(ia), dev(weight), topb, embed_bias=dev(eb))
+    assert_bitexact(topb.cpu().numpy(), topb_ref, "Euclid scores of the fused call, Embed bias")
+    cb_ref, n0b_ref, _ = oracle.simcross_forward(0, qb, ab)
+    capi.embed_simcross_forward(0, dev(iq), dev(ia), dev(weight), ctop, norm0=n0, norm1=n1, embed_bias=dev(eb))
+    assert_close(ctop.cpu().numpy(), cb_ref, TOL, "cosine scores of the fused call, Embed bias")
+    assert_close(n0.cpu().numpy(), n0b_ref, TOL, "norm0, Embed bias")
     # ids outside the table are clamped like mms_embed_forward_f32
     iq2 = iq.copy(); iq2[0, 0] = -3.0; iq2[-1, -1] = K + 5.0
     iq2c = iq2.copy(); iq2c[0, 0] = 0.0; iq2c[-1, -1] = K - 1.0
@@ -112,6 +124,13 @@ def test_embed_fused_into_bilinear_forward(cfg, oracle, hiplib):
     top2 = torch.full(top_ref.shape, float("nan"), device="cuda")
     capi.simcross_forward(2, qd, ad, top2, W=Wd, bias=bd)
     assert_bitexact(top.cpu().numpy(), top2.cpu().numpy(), "fused == Embed, Embed, SimCross")
+    # with the Embed layers' bias blob
+    eb = dev(r.uniform(-0.3, 0.3, D).astype(np.float32))
+    capi.embed_forward(dev(iq).view(-1), wd, qd.view(N * W1, D), bias=eb)
+    capi.embed_forward(dev(ia).view(-1), wd, ad.view(N * W2, D), bias=eb)
+    capi.simcross_forward(2, qd, ad, top2, W=Wd, bias=bd)
+    capi.embed_simcross_bilinear_forward(dev(iq), dev(ia), wd, Wd, bd, top, embed_bias=eb)
+    assert_bitexact(top.cpu().numpy(), top2.cpu().numpy(), "fused == Embed, Embed, SimCross (Embed bias)")
 
 
 def test_embed_fused_bilinear_refuses_other_geometries(hiplib):

@@ -121,6 +121,30 @@ def test_network_v4_path_layers_run_from_the_net_file(L, oracle, tmp_path):
     assert same(net.blob("mrr").data.ravel()[0], rr_ref)
     assert same(net.blob("auc").data.ravel()[0], auc_ref)
 
+    # the same scores straight from the word ids ("fuse_embed_scoring": one launch, w2v_q / w2v_a never written),
+    # with a non-zero Embed bias as after training: the bits of Embed, Embed, SimCross
+    eq.blobs[1].data[...] = r.uniform(-0.2, 0.2, eq.blobs[1].shape).astype(np.float32)
+    net2 = L.Net(open(FIXTURE).read().replace("__SOURCE__", str(src)), phase="TEST")
+    pb2 = net2.blob("prob"); pb2.reshape(B, 2); pb2.data[...] = prob
+    net2.set_option("fuse_embed_scoring", 1)
+    assert net2.SetUp() == 7 and net2.num_fused == 1
+    for name, bi in (("w2v_q", 0), ("w2v_q", 1), ("sim_cross", 0), ("sim_cross", 1)):
+        net2.layer(name).blobs[bi].data[...] = net.layer(name).blobs[bi].data
+    net2.blob("w2v_q").data[...] = -7.0
+    net2.Forward()                                           # batch 0 of the file again (a fresh HDF5Data layer)
+    assert (net2.blob("w2v_q").data == -7.0).all(), "the Embed top must not be written"
+    net3 = L.Net(open(FIXTURE).read().replace("__SOURCE__", str(src)), phase="TEST")
+    pb3 = net3.blob("prob"); pb3.reshape(B, 2); pb3.data[...] = prob
+    assert net3.SetUp() == 7 and net3.num_fused == 0
+    for name, bi in (("w2v_q", 0), ("w2v_q", 1), ("sim_cross", 0), ("sim_cross", 1)):
+        net3.layer(name).blobs[bi].data[...] = net.layer(name).blobs[bi].data
+    net3.Forward()
+    assert np.abs(net3.blob("sim_cross").data - net.blob("sim_cross").data).max() > 1e-3   # the bias matters
+    assert_bitexact(net2.blob("sim_cross").data, net3.blob("sim_cross").data)
+    with pytest.raises(KeyError):
+        net2.set_option("no_such_option", 1)
+    eq.blobs[1].data[...] = 0
+
     # all forwards, then all backwards (net.cpp:581-591): dW / dbias of SimCross and the shared table's gradient
     dT = r.standard_normal(top_ref.shape).astype(np.float32)
     net.blob("sim_cross").diff[...] = dT
