@@ -178,6 +178,38 @@ def test_hdf5_snapshot_round_trip(tmp_path):
         L.Snapshot(bad)
 
 
+def test_mutated_hdf5_snapshots_never_crash(tmp_path):
+    """Byte flips, truncations and wild 8-byte addresses in an HDF5 snapshot (nested groups: link entries, symbol
+    table messages, heaps): every mutant either parses or raises IOError -- the process never dies."""
+    import random
+    r = np.random.default_rng(0)
+    p = tmp_path / "s.caffemodel.h5"
+    L.save_snapshot(p, "qa", raw_layers=[("sim", "SimCross", [r.standard_normal((4, 7, 7)).astype(np.float32),
+                                                              r.standard_normal((4, 3, 2)).astype(np.float32)]),
+                                         ("embed", "Embed", [r.standard_normal((30, 5)).astype(np.float32)])], hdf5=True)
+    base = p.read_bytes()
+    random.seed(1)
+    parsed = rejected = 0
+    q = tmp_path / "m.h5"
+    for it in range(1500):
+        b = bytearray(base)
+        if it % 3 == 0:
+            for _ in range(random.randint(1, 4)):
+                b[random.randrange(len(b))] = random.randrange(256)
+        elif it % 3 == 1:
+            b = b[:random.randrange(8, len(b))]
+        else:
+            i = random.randrange(len(b) - 8)
+            b[i:i + 8] = random.choice([0, 1, len(b) - 1, 2 ** 32, 2 ** 63, random.randrange(len(b))]).to_bytes(8, "little")
+        q.write_bytes(bytes(b))
+        try:
+            L.Snapshot(q).layers()
+            parsed += 1
+        except (IOError, ValueError):
+            rejected += 1
+    assert parsed + rejected == 1500 and rejected > 100
+
+
 def test_writer_parsed_by_protobuf_runtime(tmp_path):
     r = np.random.default_rng(2)
     raw = [("sim", "SimCross", [r.standard_normal((4, 7, 7)).astype(np.float32),
