@@ -1657,7 +1657,9 @@ static size_t cross_bwd_lane_lds(bool exact, int W1, int W2) {
 // the lane kernel pays when there are enough pairs to give every SIMD a wave and the grids are narrow
 static bool cross_bwd_lane_ok(bool exact, int N, int W1, int W2, int D) {
   const bool width = W2 == 8 || W2 == 16 || W2 == 20 || W2 == 24 || W2 == 32 || W2 == 40 || W2 == 48;
-  return !exact && width && D <= 64 && N >= 512 && cross_bwd_lane_lds(exact, W1, W2) <= 64 * 1024;
+  // reference rounding: 20 bytes of coefficients per (j,k); beyond ~16 KB per wave the table limits occupancy and
+  // the tiled kernel wins (1517 x 40 x 40 x 50: 236 vs 183 us; 4096 x 20 x 20 x 50: 50 vs 92 us)
+  return width && D <= 64 && N >= 512 && cross_bwd_lane_lds(exact, W1, W2) <= (exact ? 16 : 64) * 1024;
 }
 
 // ================================ dispatch ==================================

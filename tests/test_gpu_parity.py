@@ -53,6 +53,7 @@ EUCLID_SHAPES = [
     (513, 7, 8, 33),     # ... narrowest instantiated width
     (520, 47, 48, 64),   # ... its largest geometry
     (515, 5, 24, 10),
+    (530, 20, 20, 50),   # ... small enough for its reference-rounding variant
 ]
 
 
