@@ -1181,7 +1181,7 @@ static bool pair_bwd_eligible(int N, int W1, int W2, int D, int M) {
 }
 
 // top = SimCross_bilinear(Embed(index_q), Embed(index_a)) in ONE launch, for the word-grid geometries the two
-// fused forward kernels cover (W1, W2 <= 48, D <= 64): embed_layer.cpp:135-152 (bias_term false) followed by
+// fused forward kernels cover (W1, W2 <= 48, D <= 64): embed_layer.cpp:135-152 (embed_bias: the Embed layers' bias blob or null) followed by
 // sim_cross_layer.cpp:140-161, the gather done by the staging loads.  Same kernels, same operand values: the
 // bits of mms_embed_forward_f32 x2 followed by mms_simcross_forward_f32.  Other geometries: MMS_ERR_UNSUPPORTED.
 int embed_bilinear_forward(int N, int W1, int W2, int D, int M, int K, const float* index_q,

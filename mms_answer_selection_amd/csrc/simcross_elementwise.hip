@@ -1883,8 +1883,9 @@ int simcross_elementwise_forward(int mode, int N, int W1, int W2, int D,
   return launch_status();
 }
 
-// top = SimCross(Embed(index_q), Embed(index_a)) for dist_mode 0 / 1, no Embed bias (the driver's
-// embedding layers have bias_term false, do_trec_qa_clean.py:462): embed_layer.cpp:135-152 followed by
+// top = SimCross(Embed(index_q), Embed(index_a)) for dist_mode 0 / 1; embed_bias = the Embed layers' bias blob
+// (the driver's layers have one: `bias_term` stays at its default, do_trec_qa_clean.py:462-467) or null:
+// embed_layer.cpp:135-152 followed by
 // sim_cross_layer.cpp:96-139, with the gather done by SimCross's own loads.
 int embed_simcross_forward(int mode, int N, int W1, int W2, int D, int K, const float* index_q,
                            const float* index_a, const float* weight, const float* embed_bias, float* top,

@@ -48,7 +48,7 @@ def test_embed_forward_backward(cfg, oracle, hiplib):
 @pytest.mark.parametrize("cfg", [(1517, 40, 40, 50, 20000), (1100, 16, 24, 50, 300), (7, 40, 40, 50, 100),
                                  (5, 9, 13, 33, 40), (3, 40, 40, 300, 500), (600, 1, 1, 20, 64)])
 def test_embed_fused_into_simcross_forward(cfg, oracle, hiplib):
-    """mms_embed_simcross_forward_f32 == Embed (no bias) followed by SimCross: Euclidean scores carry the
+    """mms_embed_simcross_forward_f32 == Embed (without and with its bias blob) followed by SimCross: Euclidean scores carry the
     CPU's bits; cosine 1e-5.  Covers the pair-image kernel (many pairs, D = 50) and the generic tiles."""
     from mms_answer_selection_amd import capi
     N, W1, W2, D, K = cfg
