@@ -441,8 +441,10 @@ __global__ __launch_bounds__(64 * WPB) void euclid_block_kernel(
     }
   }
   if (FWD) {
-    if (ST4 > D4C && tid < R * (ST4 - D4C))                 // zero tail of each image
-      lds4[(tid / (ST4 - D4C)) * ST4 + D4C + tid % (ST4 - D4C)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (ST4 > D4C) {                              // zero tail of each image
+      if (tid < R * (ST4 - D4C))
+        lds4[(tid / (ST4 - D4C)) * ST4 + D4C + tid % (ST4 - D4C)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (SPAN == WPB) __syncthreads(); else wave_lds_sync();
     const int wave = tid >> 6, lane = tid & 63;
     const int grp = lane >> 5, j = lane & 31;
@@ -1621,7 +1623,11 @@ __global__ __launch_bounds__(64) void cross_bwd_lane_kernel(
     // (this form: 39.5 us; cross_bwd_tiled_kernel: 62): a second row buffer (ping-pong) needs 290 VGPRs = one
     // wave per SIMD, 61 us; re-loading each entry right after its use 44 us; q staged through LDS as well 42.5 us.
     // What bounds it is the LDS return path -- every wave reads its whole 12.8 KB table for all 64 lanes, 18 us
-    // of LDS cycles per CU -- next to the VALU issue of the SIMDs that hold two of the 1517 waves.
+    // of LDS cycles per CU -- next to the VALU issue of the SIMDs that hold two of the 1517 waves.  The
+    // coefficients on the SCALAR path instead (a table in a workspace written by a first launch, read through
+    // wave-uniform addresses: five s_load_dwordx16 per row, SGPR operands of the packed multiplies) was built and
+    // measured: 61 us -- 80 SGPRs per row leave no room to run the loads ahead, so each row exposes its
+    // scalar-cache misses (the 19 MB table streams through once).
     float qv = qn[0];
     for (int j = 0; j < W1; ++j) {
       const float qnext = qn[(size_t)min(j + 1, W1 - 1) * D];
