@@ -128,12 +128,13 @@ int mms_simcross_backward_f32(int dist_mode, int N, int W1, int W2, int D, int M
                               float* dW, float* dbias, void* workspace,
                               size_t workspace_bytes, void* stream);
 
-/* Forward immediately followed by Backward with a top_diff known up front
- * (the `caffe time` loop, tools/caffe.cpp:349-361, and any net whose loss
- * gradient does not depend on this layer's output), in ONE launch for
- * dist_mode 0/1: q and a are read once, top/dq/da written once.  Results are
- * identical to the two calls above.  dist_mode 2 runs the two passes
- * back to back on `stream`. */
+/* Forward and Backward in ONE launch, for hosts that hold top_diff BEFORE the forward runs
+ * (dist_mode 0/1: q and a are read once, top/dq/da written once; dist_mode 2 runs the two passes
+ * back to back on `stream`).  Results are identical to the two calls above.  NOT reachable from
+ * the reference's callers: a Caffe Net and `caffe time` alike run every layer's Forward, then every
+ * layer's Backward (net.cpp:535-546, 581-591; tools/caffe.cpp:349-361), so a Layer binds the two
+ * calls above -- that pair of launches is what bench.py reports; this entry point is a labelled
+ * variant there. */
 int mms_simcross_forward_backward_f32(int dist_mode, int N, int W1, int W2,
                                       int D, int M, const float* q,
                                       const float* a, const float* W,
