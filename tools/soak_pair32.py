@@ -23,7 +23,11 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     dq_ref, da_ref, _, _ = O.simcross_backward(1, q, a, top_ref, dT)
     qd, ad, dTd = (torch.from_numpy(x).cuda() for x in (q, a, dT))
     top = torch.empty(N, 1, 1, 1, device="cuda"); dq = torch.empty_like(qd); da = torch.empty_like(ad)
-    capi.simcross_forward_backward(1, qd, ad, dTd, top, dq, da)
+    if seed % 2:      # the Layer-API pair of launches (row-aligned forward, workgroup-dense backward) ...
+        capi.simcross_forward(1, qd, ad, top)
+        capi.simcross_backward(1, qd, ad, top, dTd, dq, da)
+    else:             # ... or the one-launch variant
+        capi.simcross_forward_backward(1, qd, ad, dTd, top, dq, da)
     t, g, h = top.cpu().numpy(), dq.cpu().numpy(), da.cpu().numpy()
     m = int((t.view(np.uint32) != top_ref.view(np.uint32)).sum() + (g.view(np.uint32) != dq_ref.view(np.uint32)).sum()
             + (h.view(np.uint32) != da_ref.view(np.uint32)).sum())
