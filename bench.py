@@ -23,7 +23,12 @@ events, max over ranks -- gives `value`, `ms_per_step` and `roofline`; the MEDIA
 reported (all repeats are in `config.repeats_ms_per_step`).  Steps walk a ring of RING distinct
 batches (RING x 19.7 MB > 1 GiB >> 256 MiB of Infinity Cache) continuing where the warm-up stopped,
 and the caches are flushed (a 512 MiB fill) before the warm-up, so every timed step reads its q and
-a from HBM ("cold"); `--warm` re-uses one batch instead.  Steps are captured into hipGraphs of up
+a from HBM ("cold"); `--warm` re-uses one batch instead.  Between each repeat's opening fence and its
+start event, `--lead-in` (64) UNTIMED steps of the same walk are enqueued on ring slots other than
+the region's: the device is busy while the host enqueues the start event and the region's first
+hipGraph, so a short region (the driver's --steps 20) does not count host submission latency as
+kernel time; what remains of a short region's fixed cost (two event packets and a graph boundary,
+about 9 us) is visible next to `roofline.long_region`, the same walk over 2048 steps.  Steps are captured into hipGraphs of up
 to GROUP steps (launch-bound inner loop).  N > 1 shards pairs over ranks (weak scaling: 4096 pairs
 per GPU) and all-gathers the per-pair scores of each GROUP of steps with one RCCL call on a side
 stream, overlapped with the next group's compute; `--workload cfg5` / `cfg4` are the
