@@ -61,7 +61,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=4096)
     p.add_argument("--warmup", type=int, default=256)
-    p.add_argument("--group", type=int, default=64, help="steps per hipGraph / all-gather bucket")
+    p.add_argument("--group", type=int, default=256, help="steps per hipGraph / all-gather bucket")
     p.add_argument("--ring", type=int, default=64, help="distinct batches walked (HBM-cold)")
     p.add_argument("--warm", action="store_true", help="re-use one batch (Infinity-Cache-warm)")
     p.add_argument("--path", choices=["layers", "fused", "triplet"], default="layers",
@@ -565,10 +565,11 @@ def run(args):
     if rank == 0 and world == 1 and not args.no_variants:
         if "roofline" in out:
             out["roofline"].update(per_kernel_roofline(torch, capi))
-            fl = out["roofline"]["launch_floor"]["us_per_empty_launch"] * launches_per_step
+            fl = out["roofline"]["launch_floor"]["us_per_empty_launch"] * launches_per_step + \
+                out["roofline"]["launch_floor"]["us_per_graph_launch"] / max(G, 1)
             above = max(out["roofline"]["avg_step_us_hip_events"] - fl, 1e-3)
             out["roofline"]["launch_floor"].update({
-                "launches_per_step": launches_per_step, "us_per_step": fl,
+                "launches_per_step": launches_per_step, "steps_per_graph": G, "us_per_step": fl,
                 "step_us_above_launch_floor": above,
                 "GBps_above_launch_floor": B_UNFUSED / (above * 1e-6) / 1e9,
                 "frac_ceiling_if_data_were_free": B_UNFUSED / (fl * 1e-6) / 1e9 / HBM_PEAK_GBS})
@@ -620,29 +621,39 @@ def per_kernel_roofline(torch, capi):
         res[name] = {"us_per_launch": us, "algorithmic_bytes": nbytes,
                      "achieved_GBps": nbytes / (us * 1e-6) / 1e9,
                      "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
-    # what a launch costs by itself under the same protocol: 256 empty kernels (256 x 512 threads) per region
-    cap = torch.cuda.Stream()
-    cap.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(cap):
-        gph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gph, stream=cap):
-            for i in range(32):
-                capi.null_launch(256)
-    torch.cuda.current_stream().wait_stream(cap)
-    ts = []
-    for rep in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for r in range(8):
-            gph.replay()
-        e1.record()
+    # what a launch costs by itself under the same protocol: graphs of 16 and of 128 EMPTY kernels (256 x 512
+    # threads) replayed back to back -- the per-kernel floor inside a graph and the cost of a hipGraphLaunch boundary
+    # separate as the slope and the intercept (tools/graphbound.hip: a graph of n empty kernels takes 6.5 + 1.56 n us)
+    per = {}
+    for nk in (16, 128):
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            gph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gph, stream=cap):
+                for i in range(nk):
+                    capi.null_launch(256)
+        torch.cuda.current_stream().wait_stream(cap)
+        gph.replay()
         torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) * 1e3 / 256)
-    floor = median(ts)
+        ts = []
+        for rep in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for r in range(16):
+                gph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / 16)
+        per[nk] = median(ts)
+    floor = (per[128] - per[16]) / 112.0
+    boundary = per[16] - 16 * floor
     return {"per_kernel_cold": res,
-            "launch_floor": {"us_per_empty_launch": floor,
-                             "note": "an EMPTY kernel (mms_null_launch, 256 x 512 threads) replayed under the same "
-                                     "hipGraph protocol: a step of L launches cannot take less than L x this"}}
+            "launch_floor": {"us_per_empty_launch": floor, "us_per_graph_launch": boundary,
+                             "note": "EMPTY kernels (mms_null_launch, 256 x 512 threads) in hipGraphs of 16 and 128, "
+                                     "replayed back to back: slope = what a kernel node costs by itself, intercept = what "
+                                     "a hipGraphLaunch costs by itself; a step of L launches in graphs of G steps cannot "
+                                     "take less than L x slope + intercept / G"}}
 
 
 def run_cfg5(args, torch, dist, capi, world, rank):
