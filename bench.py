@@ -77,6 +77,11 @@ def parse():
                    help="untimed steps of the same walk enqueued between each repeat's opening fence and its start "
                         "event (device busy and at its running clocks when the timed region's first graph arrives)")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
+                   help="graph: steps captured into hipGraphs of --group steps; eager: every kernel launched by "
+                        "itself through pre-bound C-ABI calls, the way a native Layer host does (a hipGraphLaunch "
+                        "costs 6.5 us of device time, a third of a microsecond per step in the driver's 20-step "
+                        "regions); auto = eager for the layers path when --steps < 1024, graph otherwise")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -127,6 +132,33 @@ def make_step(capi, bt, path):
             capi.triplet_euclid_step(bt.q[i], bt.a[i], bt.an[i], bt.y[i], top.view(N_PAIRS, 1),
                                      bt.sneg[i], bt.loss[i], bt.dq[i], bt.da[i], bt.dan[i],
                                      margin=0.05)
+    return step
+
+
+def make_raw_step(capi, bt, path, torch):
+    """step(slot, top_ptr) through the argument-block entry points (include/mms.h: mms_simcross_*_block_f32): one
+    pre-filled block per ring slot, two ctypes arguments per call -- ~1.3 us of host time per launch instead of ~4
+    for the 21-argument form, so the host stays ahead of a 3.8-us kernel without a hipGraph."""
+    import ctypes as C
+    lib = capi.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    blocks = []
+    for i in range(bt.q.shape[0]):
+        blk = capi.SimCrossArgs()
+        blk.dist_mode, blk.N, blk.W1, blk.W2, blk.D, blk.M = 1, N_PAIRS, 1, 1, DIM, 1
+        blk.q, blk.a = bt.q[i].data_ptr(), bt.a[i].data_ptr()
+        blk.top_diff, blk.dq, blk.da = bt.dT[i].data_ptr(), bt.dq[i].data_ptr(), bt.da[i].data_ptr()
+        blk.propagate_down0 = blk.propagate_down1 = 1
+        blocks.append((blk, C.byref(blk)))
+    fwd, bwd = lib.mms_simcross_forward_block_f32, lib.mms_simcross_backward_block_f32
+    if path != "layers":
+        return None
+
+    def step(i, top):
+        blk, ref = blocks[i]
+        blk.top = top
+        if fwd(ref, st) | bwd(ref, st):
+            raise RuntimeError("C ABI call failed")
     return step
 
 
@@ -215,9 +247,12 @@ class Region:
     """Steps [first, first+k) of the ring walk, cut into hipGraphs of at most G steps.  Step i reads ring
     slot i % ring and writes its scores into row (i - chunk start) of a bucket; chunks alternate buckets."""
 
-    def __init__(self, torch, step, ring, G, buckets, use_graph):
+    def __init__(self, torch, step, ring, G, buckets, use_graph, raw_step=None):
         self.torch, self.step, self.ring, self.G = torch, step, ring, G
         self.buckets, self.use_graph = buckets, use_graph
+        self.raw_step = raw_step                     # eager mode: pre-bound calls on raw pointers
+        self.bucket_ptr = [b.data_ptr() for b in buckets]
+        self.row_bytes = buckets[0][0].numel() * 4
         self.graphs = {}
         self.nchunk = 0
 
@@ -231,6 +266,11 @@ class Region:
         return out
 
     def body(self, i0, cnt, bi):
+        if self.raw_step is not None and not self.use_graph:
+            base, rb, ring, raw = self.bucket_ptr[bi], self.row_bytes, self.ring, self.raw_step
+            for s in range(cnt):
+                raw((i0 + s) % ring, base + s * rb)
+            return
         b = self.buckets[bi]
         for s in range(cnt):
             self.step((i0 + s) % self.ring, b[s])
@@ -370,6 +410,9 @@ def time_regions(torch, dist, world, main, repeats, run_one, pad=None):
         _EVENTS["ev"] = _TimingEvents(torch)
     ev = _EVENTS["ev"]
     ms, wall = [], []
+    import gc
+    gc_was = gc.isenabled()
+    gc.disable()                                     # an eager region must not lose the host to a collection
     for r in range(repeats):
         e0, e1 = ev.pair()
         fence()
@@ -382,6 +425,8 @@ def time_regions(torch, dist, world, main, repeats, run_one, pad=None):
         fence()
         wall.append((time.perf_counter() - t0) * 1e3)
         ms.append(ev.elapsed_ms(e0, e1))
+    if gc_was:
+        gc.enable()
     t = torch.tensor(ms + wall, dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -411,8 +456,13 @@ def run(args):
     comm = torch.cuda.Stream() if world > 1 else None
     bucket_free = [torch.cuda.Event() for _ in range(2)]   # gather of that bucket finished
     main = torch.cuda.current_stream()
-    use_graph = not args.no_graph
-    reg = Region(torch, step, ring, G, buckets, use_graph)
+    raw_step = make_raw_step(capi, bt, args.path, torch) if args.path == "layers" else None
+    # auto: short regions (the driver's --steps 20) launch kernel by kernel -- one hipGraphLaunch per region would cost
+    # 6.5 us of device time, a third of a microsecond per step (8.05-8.11 vs 7.71 us); long regions keep hipGraphs of
+    # --group steps, where the host never has to keep pace (7.57 us in every repeat vs 7.6-8.2 eager)
+    eager = args.no_graph or args.launch == "eager" or (args.launch == "auto" and raw_step is not None and K < 1024)
+    use_graph = not eager
+    reg = Region(torch, step, ring, G, buckets, use_graph, raw_step)
 
     # eager pass over every code path (instantiates kernels), then the graphs of the warm-up and of
     # every timed repeat -- all captured before anything is timed
@@ -496,6 +546,9 @@ def run(args):
                                     "HBM-cold: ring of %d batches (%.2f GiB), caches flushed before the warm-up, "
                                     "timed steps continue the ring walk" % (ring, ring * 19.7e6 / 2**30),
                        "hip_graph_group": G if use_graph else 0,
+                       "launch": "hipGraphs of %d steps" % G if use_graph else
+                                 "eager: every kernel launched by itself through pre-bound C-ABI calls on the launch "
+                                 "stream (host ~2 us per launch, ahead of the device behind the lead-in steps)",
                        "clock": "HIP events (" + _EVENTS["ev"].kind + ") on the launch stream inside barrier+synchronize fences, max over ranks; "
                                 "median of %d repeats of the %d-step region; %d untimed lead-in steps of the same "
                                 "walk run between each opening fence and its start event (the region's first "
@@ -529,7 +582,7 @@ def run(args):
     # N > 1: the same walk with the scores all-gathered after EVERY step (no bucketing), for the record
     if world > 1 and not args.no_variants:
         K2 = min(K, 256)
-        reg1 = Region(torch, step, ring, 1, buckets, use_graph)
+        reg1 = Region(torch, step, ring, 1, buckets, use_graph, raw_step)
         first = Wm + args.repeats * K
         ch = [reg1.chunks(first + r * K2, K2) for r in range(3)]
         reg1.capture(ch)
@@ -551,7 +604,7 @@ def run(args):
         first = Wm + args.repeats * K
         G3 = max(1, min(args.group, K3))
         reg3 = Region(torch, step, ring, G3, [torch.empty(G3, N_PAIRS, 1, 1, 1, device="cuda") for _ in range(2)],
-                      use_graph)
+                      use_graph, raw_step)
         ch3 = [reg3.chunks(first + r * K3, K3) for r in range(3)]
         reg3.capture(ch3)
         ev3, _ = time_regions(torch, dist, world, main, 3, lambda r: reg3.run(ch3[r]), pad=lead_in if Gp else None)
@@ -566,10 +619,10 @@ def run(args):
         if "roofline" in out:
             out["roofline"].update(per_kernel_roofline(torch, capi))
             fl = out["roofline"]["launch_floor"]["us_per_empty_launch"] * launches_per_step + \
-                out["roofline"]["launch_floor"]["us_per_graph_launch"] / max(G, 1)
+                (out["roofline"]["launch_floor"]["us_per_graph_launch"] / max(G, 1) if use_graph else 0.0)
             above = max(out["roofline"]["avg_step_us_hip_events"] - fl, 1e-3)
             out["roofline"]["launch_floor"].update({
-                "launches_per_step": launches_per_step, "steps_per_graph": G, "us_per_step": fl,
+                "launches_per_step": launches_per_step, "steps_per_graph": G if use_graph else 0, "us_per_step": fl,
                 "step_us_above_launch_floor": above,
                 "GBps_above_launch_floor": B_UNFUSED / (above * 1e-6) / 1e9,
                 "frac_ceiling_if_data_were_free": B_UNFUSED / (fl * 1e-6) / 1e9 / HBM_PEAK_GBS})

@@ -128,6 +128,23 @@ int mms_simcross_backward_f32(int dist_mode, int N, int W1, int W2, int D, int M
                               float* dW, float* dbias, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* The two calls above with their arguments in ONE block (same meaning, same checks, same results): for hosts
+ * whose foreign-function calls cost per argument -- ctypes, JNI, cgo -- so that launching kernel by kernel keeps
+ * ahead of the device without a hipGraph (a 21-argument ctypes call costs ~4 us of host time, one with a block
+ * pointer ~1.3 us; a kernel of this path runs 3-5 us).  The block may be reused and edited between calls. */
+typedef struct mms_simcross_args_f32 {
+  int dist_mode, N, W1, W2, D, M;
+  const float* q; const float* a; const float* W; const float* bias;   /* bias: forward only */
+  float* top;                                                          /* forward: written; backward: read */
+  float* norm0; float* norm1;
+  /* backward only */
+  int bias_term, propagate_down0, propagate_down1;
+  const float* top_diff; float* dq; float* da; float* dW; float* dbias;
+  void* workspace; size_t workspace_bytes;
+} mms_simcross_args_f32;
+int mms_simcross_forward_block_f32(const mms_simcross_args_f32* args, void* stream);
+int mms_simcross_backward_block_f32(const mms_simcross_args_f32* args, void* stream);
+
 /* Forward and Backward in ONE launch, for hosts that hold top_diff BEFORE the forward runs
  * (dist_mode 0/1: q and a are read once, top/dq/da written once; dist_mode 2 runs the two passes
  * back to back on `stream`).  Results are identical to the two calls above.  NOT reachable from

@@ -52,6 +52,8 @@ _SIGNATURES = {
     "mms_set_euclid_backward_mode": (_i, [_i]),
     "mms_get_euclid_backward_mode": (_i, []),
     "mms_null_launch": (_i, [_i, _vp]),
+    "mms_simcross_forward_block_f32": (_i, [_vp, _vp]),
+    "mms_simcross_backward_block_f32": (_i, [_vp, _vp]),
     "mms_dot_f32": (_i, [_i, _vp, _vp, _vp, _vp]),
     "mms_dot_f64": (_i, [_i, _vp, _vp, _vp, _vp]),
     "mms_set_f16_distance_mode": (_i, [_i]),
@@ -361,6 +363,16 @@ def feed_gather_rows(src, first, rows, dst, perm=None):
                                          _ptr(perm, "perm", True, dtype=torch.int32), first,
                                          _ptr(dst, "dst"), _stream()),
           "mms_feed_gather_rows_f32")
+
+
+class SimCrossArgs(C.Structure):
+    """include/mms.h: mms_simcross_args_f32 -- the arguments of the SimCross forward / backward in one block."""
+    _fields_ = [("dist_mode", C.c_int), ("N", C.c_int), ("W1", C.c_int), ("W2", C.c_int), ("D", C.c_int), ("M", C.c_int),
+                ("q", C.c_void_p), ("a", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
+                ("top", C.c_void_p), ("norm0", C.c_void_p), ("norm1", C.c_void_p),
+                ("bias_term", C.c_int), ("propagate_down0", C.c_int), ("propagate_down1", C.c_int),
+                ("top_diff", C.c_void_p), ("dq", C.c_void_p), ("da", C.c_void_p), ("dW", C.c_void_p), ("dbias", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 def null_launch(workgroups=256):

@@ -197,6 +197,18 @@ int mms_simcross_backward_f32(int dist_mode, int N, int W1, int W2, int D, int M
                                        dq, da, s);
 }
 
+int mms_simcross_forward_block_f32(const mms_simcross_args_f32* p, void* stream) {
+  if (!p) return MMS_ERR_INVALID_ARG;
+  return mms_simcross_forward_f32(p->dist_mode, p->N, p->W1, p->W2, p->D, p->M, p->q, p->a, p->W, p->bias, p->top,
+                                  p->norm0, p->norm1, p->workspace, p->workspace_bytes, stream);
+}
+int mms_simcross_backward_block_f32(const mms_simcross_args_f32* p, void* stream) {
+  if (!p) return MMS_ERR_INVALID_ARG;
+  return mms_simcross_backward_f32(p->dist_mode, p->N, p->W1, p->W2, p->D, p->M, p->q, p->a, p->W, p->bias_term,
+                                   p->top, p->top_diff, p->norm0, p->norm1, p->propagate_down0, p->propagate_down1,
+                                   p->dq, p->da, p->dW, p->dbias, p->workspace, p->workspace_bytes, stream);
+}
+
 int mms_simcross_forward_backward_f32(int dist_mode, int N, int W1, int W2, int D, int M,
                                       const float* q, const float* a, const float* W,
                                       const float* bias, const float* top_diff, float* top,

@@ -147,6 +147,35 @@ int main(int argc, char** argv) {
     }
   };
 
+  // EAGER launches (no hipGraph) of the Layer-API pair for 20 steps, the host running ahead of the device behind an
+  // untimed lead-in: what a native host that launches kernel by kernel sees (no 6.5-us graph-launch boundary)
+  if (argc > 1 && atoi(argv[1]) == 2) {
+    auto pair = [&](Slot& x) {
+      mms_simcross_forward_f32(1, N, 1, 1, D, 1, x.q, x.a, nullptr, nullptr, x.top, nullptr, nullptr, nullptr, 0, st);
+      mms_simcross_backward_f32(1, N, 1, 1, D, 1, x.q, x.a, nullptr, 0, x.top, x.dT, nullptr, nullptr, 1, 1, x.dq, x.da, nullptr, nullptr, nullptr, 0, st);
+    };
+    hipGraph_t g; hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int k = 0; k < 32; ++k) pair(s[32 + k]);
+    CK(hipStreamEndCapture(st, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    for (int K : {20, 64, 256}) {
+      std::vector<float> times;
+      for (int rep = 0; rep < 7; ++rep) {
+        CK(hipStreamSynchronize(st));
+        for (int i = 0; i < 8; ++i) CK(hipGraphLaunch(ge, st));      // ~2 ms of lead-in
+        CK(hipEventRecord(e0, st));
+        for (int k = 0; k < K; ++k) pair(s[(rep * 7 + k) % 32]);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        times.push_back(ms * 1e3f / K);
+      }
+      std::sort(times.begin(), times.end());
+      printf("EAGER mms fwd + mms bwd, %3d steps per region: median %7.3f us/step  min %7.3f\n", K, times[3], times[0]);
+    }
+    return 0;
+  }
   run("copy2 (1 float4/thread)", [&](Slot& x, hipStream_t t) {
     hipLaunchKernelGGL(copy2_kernel, dim3((n4 + 255) / 256), dim3(256), 0, t, (const float4*)x.q, (const float4*)x.a, (float4*)x.dq, (float4*)x.da, n4); }, 4.0 * nb);
   run("copy2 pair-structured, nt stores", [&](Slot& x, hipStream_t t) {
