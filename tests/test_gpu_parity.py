@@ -731,3 +731,32 @@ def test_error_codes(hiplib):
     assert L.mms_error_string(3).decode().startswith("workspace")
     with pytest.raises(capi.MMSError):
         capi.simcross_forward(1, q.cpu(), q.cpu(), top.cpu())     # host tensors are refused
+
+
+def test_argument_block_entry_points_match_the_plain_calls(oracle, hiplib):
+    """mms_simcross_forward_block_f32 / _backward_block_f32 (arguments in one struct, for FFI hosts) are the two
+    SimCross calls: same bits, same error for a bad block."""
+    import ctypes as C
+    from mms_answer_selection_amd import capi
+    r = rng(91)
+    N, D = 37, 300
+    q, a = qa(r, N, 1, 1, D)
+    dT = r.standard_normal((N, 1, 1, 1)).astype(np.float32)
+    top_ref, _, _ = oracle.simcross_forward(1, q, a)
+    dq_ref, da_ref, _, _ = oracle.simcross_backward(1, q, a, top_ref, dT)
+    qd, ad, dTd = dev(q), dev(a), dev(dT)
+    top, gq, ga = nan_like(top_ref.shape), nan_like(q.shape), nan_like(a.shape)
+    blk = capi.SimCrossArgs()
+    blk.dist_mode, blk.N, blk.W1, blk.W2, blk.D, blk.M = 1, N, 1, 1, D, 1
+    blk.q, blk.a, blk.top = qd.data_ptr(), ad.data_ptr(), top.data_ptr()
+    blk.top_diff, blk.dq, blk.da = dTd.data_ptr(), gq.data_ptr(), ga.data_ptr()
+    blk.propagate_down0 = blk.propagate_down1 = 1
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert hiplib.mms_simcross_forward_block_f32(C.byref(blk), st) == 0
+    assert hiplib.mms_simcross_backward_block_f32(C.byref(blk), st) == 0
+    assert_bitexact(host(top), top_ref, "top")
+    assert_bitexact(host(gq), dq_ref, "dq")
+    assert_bitexact(host(ga), da_ref, "da")
+    assert hiplib.mms_simcross_forward_block_f32(None, st) != 0
+    blk.q = None
+    assert hiplib.mms_simcross_forward_block_f32(C.byref(blk), st) != 0
