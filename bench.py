@@ -872,7 +872,9 @@ if DEFAULT_BWD_MODE not in ("fp32", "reference"):
 def variants(torch, capi, args):
     """Short interleaved measurements of the other entry points / residency, same device."""
     res = {}
-    K, G = 512, 16
+    # 128 steps per hipGraph: a hipGraphLaunch costs ~6.5 us of device time by itself (tools/graphbound.hip), which at
+    # 16 steps per graph (round 1) added 0.4 us to every per-step figure below
+    K, G = 1024, 128
     for name, path, ring in (("fused_cold", "fused", 64), ("fused_warm", "fused", 1),
                              ("fused_cold_reference_rounding_bwd", "fused", 64),
                              ("layers_cold", "layers", 64), ("layers_warm", "layers", 1),
@@ -886,11 +888,10 @@ def variants(torch, capi, args):
         bt = Batches(torch, ring, path, 0)
         step = make_step(capi, bt, path)
         top = torch.empty(G, N_PAIRS, 1, 1, 1, device="cuda")
-        ng = max(1, ring // G)
+        ng = 1 if ring == 1 else 3                    # three graphs walk the ring (G is a multiple of it) in turn
         graphs = []
-        for gi in range(ng):
-            for s in range(G):
-                step((gi * G + s) % ring, top[s])
+        for s in range(min(G, max(ring, 1))):
+            step(s % ring, top[s])
         torch.cuda.synchronize()
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
@@ -930,7 +931,7 @@ def variants(torch, capi, args):
     return res
 
 
-def _graph_time(torch, fn, iters=16, reps=6):
+def _graph_time(torch, fn, iters=64, reps=6):
     """Median us per call of `fn`, replayed from a hipGraph of `iters` calls (cache-warm)."""
     for _ in range(2):
         fn()
