@@ -976,7 +976,7 @@ def other_configs(torch, capi):
     def cfg3():
         capi.simmatrix_forward(q, a, W, top, scr)
         capi.simmatrix_backward(q, a, W, dT, dq, da, dW, ws=ws, qw=scr)
-    us = _graph_time(torch, cfg3, iters=4)
+    us = _graph_time(torch, cfg3, iters=16)
     flops = 2.0 * N * K * K + 2.0 * N * K + 6.0 * N * K * K        # the reference's 4 products
     done = 2.0 * N * K * K + 2.0 * N * K + 4.0 * N * K * K         # executed: Q.W once
     out["cfg3_simmatrix_16384x300x300_fwd_bwd"] = {
@@ -988,7 +988,7 @@ def other_configs(torch, capi):
     def cfg3_nocache():
         capi.simmatrix_forward(q, a, W, top, scr)
         capi.simmatrix_backward(q, a, W, dT, dq, da, dW, ws=ws)
-    us = _graph_time(torch, cfg3_nocache, iters=4)
+    us = _graph_time(torch, cfg3_nocache, iters=16)
     out["cfg3_simmatrix_recomputing_backward"] = {
         "us_per_step": us, "pairs_per_s": N / (us * 1e-6), "TFLOPs": flops / us / 1e6,
         "frac_mfma_fp32_peak": flops / (us * 1e-6) / 157.3e12, "bound": "mfma", "dtype": "f32"}
@@ -1005,7 +1005,7 @@ def other_configs(torch, capi):
         def cfg1():
             capi.simcross_forward(2, q1, a1, t1, W=W1, bias=b1, ws=ws)
             capi.simcross_backward(2, q1, a1, t1, dT1, dq1, da1, W=W1, bias_term=True, dW=dW1, dbias=db1, ws=ws)
-        us = _graph_time(torch, cfg1, iters=4)
+        us = _graph_time(torch, cfg1, iters=32)
         fl = 2.0 * N1 * M1 * Wd * D1 * (D1 + Wd) + 8.0 * N1 * M1 * Wd * D1 * (D1 + Wd)
         out["cfg1_bilinear_%dx%dx%dx%d_M%d_fwd_bwd" % (N1, Wd, Wd, D1, M1)] = {
             "us_per_step": us, "pairs_per_s": N1 / (us * 1e-6), "TFLOPs": fl / us / 1e6,
@@ -1023,7 +1023,7 @@ def other_configs(torch, capi):
         def prl():
             capi.pairrank_forward(pa, pb, py, po, ps, pl, margin=0.1, ws=ws)
             capi.pairrank_backward(py, po, ps, pda, pdb)
-        us = _graph_time(torch, prl, iters=8)
+        us = _graph_time(torch, prl, iters=32)
         out["pairrankloss_%dx1_fwd_bwd" % cnt] = {
             "us_per_step": us, "pairs_per_s": cnt / (us * 1e-6),
             "frac_hbm_unfused_bytes": 4.0 * 10 * cnt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": "hbm / launch"}

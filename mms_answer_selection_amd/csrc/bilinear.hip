@@ -585,6 +585,46 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// SimMatrix backward: the split-K reduction of dW and the transpose of W (the dq product's k-major B operand) are
+// two independent ~5-us launches in a row; here they are ONE -- workgroups [0, red_blocks) reduce, the rest
+// transpose 32 x 32 tiles -- which takes a launch (1.6 us of floor + the shorter kernel) off a cfg 3 step.
+__global__ __launch_bounds__(256) void splitk_reduce_transpose_kernel(const float* __restrict__ part, int splits,
+                                                                      long long n, float* __restrict__ out,
+                                                                      int accumulate, int red_blocks,
+                                                                      const float* __restrict__ tin,
+                                                                      float* __restrict__ tout, int rows, int cols) {
+  if ((int)blockIdx.x < red_blocks) {
+    const long long stride = (long long)red_blocks * 256;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
+      float s = 0.f;
+      for (int k0 = 0; k0 < splits; k0 += 8) {       // same s-ascending order as splitk_reduce_kernel
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(long long)min(k0 + u, splits - 1) * n + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (k0 + u < splits) ? v[u] : 0.f;
+      }
+      out[e] = accumulate ? out[e] + s : s;
+    }
+    return;
+  }
+  __shared__ float tile[32][33];
+  const int tb = (int)blockIdx.x - red_blocks, tiles_x = (cols + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int c0 = (tb % tiles_x) * 32, r0 = (tb / tiles_x) * 32;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int rr = r0 + ty + 8 * u, cc = c0 + tx;
+    if (rr < rows && cc < cols) tile[ty + 8 * u][tx] = tin[(long long)rr * cols + cc];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int oc = c0 + ty + 8 * u, orr = r0 + tx;          // tout[oc][orr] = tin[orr][oc]
+    if (oc < cols && orr < rows) tout[(long long)oc * rows + orr] = tile[tx][ty + 8 * u];
+  }
+}
+
 // out[r][c] = scale[r] * x[r][c]
 __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ scale,
@@ -1430,6 +1470,14 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
                        const float* top_diff, int ppd, int pd0, int pd1, float* dq, float* da,
                        float* dW, const float* qw, void* ws, size_t ws_bytes, hipStream_t s) {
   const SimMatrixWs lay = simmatrix_ws(N, K1, K2);
+  // will the dq product take the panel kernel (and need W^T)?  Then its transpose rides in the dW reduction's launch.
+  float* const Wt_ws = (ws && ws_bytes >= lay.total) ? reinterpret_cast<float*>(static_cast<char*>(ws) + lay.wt_off) : nullptr;
+  bool dq_panel = false, wt_done = false;
+  if (pd0 && Wt_ws) {
+    PanelArgs pq = panel_args(N, K1, K2, a, K2, Wt_ws, K1, dq, K1);
+    pq.rowscale = top_diff;
+    dq_panel = panel_eligible(pq, true);
+  }
   if (ppd) {
     if (!ws || ws_bytes < lay.total) return MMS_ERR_WORKSPACE;
     char* base = static_cast<char*>(ws);
@@ -1444,8 +1492,15 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
       p.c_ks = (long long)K1 * K2;
       if (p.ksplit > 1 && panel_eligible(p, false)) {
         panel_launch(p, false, s);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks((long long)K1 * K2)), dim3(256), 0, s,
-                           part, p.ksplit, (long long)K1 * K2, dW, 1);
+        const unsigned rb = ew_blocks((long long)K1 * K2);
+        if (dq_panel) {
+          const unsigned tb = (unsigned)(((K2 + 31) / 32) * ((K1 + 31) / 32));
+          hipLaunchKernelGGL(splitk_reduce_transpose_kernel, dim3(rb + tb), dim3(256), 0, s, part, p.ksplit,
+                             (long long)K1 * K2, dW, 1, (int)rb, W, Wt_ws, K1, K2);
+          wt_done = true;
+        } else {
+          hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, part, p.ksplit, (long long)K1 * K2, dW, 1);
+        }
         dw_done = true;
       }
     }
@@ -1467,7 +1522,7 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
   bool da_done = false;
   if (pd0) {
     // dq_j = dT_j * (W a_j)   (:88, NoTrans, beta 0)
-    float* Wt = (ws && ws_bytes >= lay.total) ? reinterpret_cast<float*>(static_cast<char*>(ws) + lay.wt_off) : nullptr;
+    float* Wt = Wt_ws;
     PanelArgs p = panel_args(N, K1, K2, a, K2, Wt, K1, dq, K1);     // B(k, n) = W[n][k] = Wt[k][n]
     p.rowscale = top_diff;
     p.stream_c = 1;                             // read next by another layer, not by this call
@@ -1477,7 +1532,8 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
       p.side_in = qw; p.side_out = da; p.side_scale = top_diff; p.side_ld = K2; p.side_cols = K2;
     }
     if (Wt && panel_eligible(p, true)) {
-      hipLaunchKernelGGL(pg_transpose_kernel, dim3((K2 + 31) / 32, (K1 + 31) / 32), dim3(256), 0, s, W, Wt, K1, K2);
+      if (!wt_done)
+        hipLaunchKernelGGL(pg_transpose_kernel, dim3((K2 + 31) / 32, (K1 + 31) / 32), dim3(256), 0, s, W, Wt, K1, K2);
       panel_launch(p, true, s);
       da_done = p.side_in != nullptr;
     } else {
