@@ -518,12 +518,12 @@ def run(args):
 
     out = None
     if rank == 0:
-        launches_per_step = {"fused": 1, "layers": 2, "triplet": 2}[args.path]
+        launches_per_step = {"fused": 1, "layers": 2, "triplet": 1}[args.path]
         step_us = t_ms * 1e3 / K
         achieved = B_UNFUSED / (step_us * 1e-6) / 1e9 if args.path != "triplet" else None
         kernel = {"fused": "mms::euclid_pair32_kernel<75,true,true,...> (SimCross Euclid fwd+bwd, one launch)",
                   "layers": "mms::euclid_pair32_kernel<75,true,false,...> (Forward launch) then mms::euclid_block_kernel<75,false,true,...> (Backward launch)",
-                  "triplet": "mms::triplet32_kernel<75,...> + loss_finish_kernel"}[args.path]
+                  "triplet": "mms::triplet32_kernel<75,...>"}[args.path]
         mode = capi.get_euclid_backward_mode()
         out = {
             "metric": "QA pairs/sec (fwd+bwd) at batch 4096, 300-d; % HBM roofline",

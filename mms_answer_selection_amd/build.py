@@ -28,6 +28,10 @@ HIPCC_FLAGS = [
     "-fno-fast-math", "-Wall", "-Wno-unused-function",
     "-mllvm", "-amdgpu-kernarg-preload-count=16",
 ]
+# pairrank.hip: the arrival atomics of the fused step are issued by ONE lane and their return values are consumed
+# after the gradient stores; the atomic optimizer's wave scan + readfirstlane would pull the wait to the issue.
+HIPCC_FLAGS += os.environ.get("MMS_HIPCC_EXTRA", "").split()   # dev builds (-DMMS_STAMPS, -DMMS_ABLATE=.., ...)
+EXTRA_FLAGS = {"pairrank.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
 
 
 def _hipcc():
@@ -65,7 +69,7 @@ def build_hip(force=False, verbose=False):
         obj = os.path.join(objdir, f.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append(([_hipcc()] + cflags + ["-c", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+            jobs.append(([_hipcc()] + cflags + EXTRA_FLAGS.get(f, []) + ["-c", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
                                                 src, "-o", obj], verbose))
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as ex:

@@ -404,7 +404,8 @@ def set_f16_distance_mode(mode):
 
 
 def set_triplet_finish_mode(mode):
-    """'launch' (default): second launch sums the loss terms; 'inlaunch': the step's last workgroup does."""
+    """'inlaunch' (default): the loss is summed inside the step's one launch; 'launch': a second launch sums the terms
+    (include/mms.h: MMS_TRIPLET_FINISH_*)."""
     m = {"launch": 0, "inlaunch": 1}[mode] if isinstance(mode, str) else int(mode)
     check(lib().mms_set_triplet_finish_mode(m), "mms_set_triplet_finish_mode")
 

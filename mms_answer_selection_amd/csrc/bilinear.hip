@@ -165,6 +165,26 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
   // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const float* rs = g.rowscale ? g.rowscale + b0 * g.rs_b0 : nullptr;
   const float* ad = g.addend ? g.addend + b1 * g.ad_b1 : nullptr;
+  // everything the epilogue reads is requested before its first store (see gemm32_fast_tile)
+  float rsv[16] = {}, adv[2][16] = {}, cv[2][16] = {};
+  if (rs || ad || g.beta_one) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gi = i0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const long long gic = gi < g.M ? gi : g.M - 1;
+      rsv[r] = rs ? rs[gic] : 1.0f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gj = j0 + 32 * h + (lane & 31);
+        const long long gjc = gj < g.N ? gj : g.N - 1;
+        adv[h][r] = ad ? ad[gic * g.ldc + gjc] : 0.f;
+        cv[h][r] = g.beta_one ? C[gic * g.ldc + gjc] : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    asm volatile("" : "+v"(rsv[r]), "+v"(adv[0][r]), "+v"(adv[1][r]), "+v"(cv[0][r]), "+v"(cv[1][r]));   // in registers HERE
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int gi = i0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -174,10 +194,10 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
       const int gj = j0 + 32 * h + (lane & 31);
       if (gj >= g.N) continue;
       float v = h ? acc1[r] : acc0[r];
-      if (rs) v = rs[gi] * v;
-      if (ad) v = ad[gi * g.ldc + gj] + v;
+      if (rs) v = rsv[r] * v;
+      if (ad) v = adv[h][r] + v;
       float* c = C + gi * g.ldc + gj;
-      if (g.beta_one) v = v + *c;
+      if (g.beta_one) v = v + cv[h][r];
       *c = v;
     }
   }
@@ -339,15 +359,33 @@ __device__ __forceinline__ void gemm32_fast_tile(const GemmArgs& g, int bx, int 
   const float* rs = g.rowscale ? g.rowscale + b0 * g.rs_b0 : nullptr;
   const float* ad = g.addend ? g.addend + b1 * g.ad_b1 : nullptr;
   const int gj = j0 + wn * 32 + r;
+  // Everything the epilogue reads is requested before its first store (clamped addresses keep the loads
+  // unconditional).  Element by element -- load, use, store, next load -- every load waited with vmcnt(0) for
+  // the acknowledgement of the store before it (C may alias what is read, so the compiler cannot hoist):
+  // sixteen dependent memory round trips per thread whenever a row scale, an addend or C += was asked for.
+  float rsv[16] = {}, adv[16] = {}, cv[16] = {};
+  if (rs || ad || g.beta_one) {
+    const long long gjc = gj < g.N ? gj : g.N - 1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int gi = i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      const long long gic = gi < g.M ? gi : g.M - 1;
+      rsv[q] = rs ? rs[gic] : 1.0f;
+      adv[q] = ad ? ad[gic * g.ldc + gjc] : 0.f;
+      cv[q] = g.beta_one ? C[gic * g.ldc + gjc] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(rsv[q]), "+v"(adv[q]), "+v"(cv[q]));   // in registers HERE
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int gi = i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
     if (gi >= g.M || gj >= g.N) continue;
     float v = acc[q];
-    if (rs) v = rs[gi] * v;
-    if (ad) v = ad[gi * g.ldc + gj] + v;
+    if (rs) v = rsv[q] * v;
+    if (ad) v = adv[q] + v;
     float* c = C + gi * g.ldc + gj;
-    if (g.beta_one) { v = v + *c; *c = v; }
+    if (g.beta_one) *c = v + cv[q];
     else if (g.stream_c) __builtin_nontemporal_store(v, c);
     else *c = v;
   }
@@ -972,6 +1010,9 @@ __global__ __launch_bounds__(256) void bilinear_pair_fwd_kernel(
     wave_lds_sync_local();                         // tw is rewritten by this wave's next item
     float* tn = top + ((size_t)n * M + m) * W1 * W2;
 #pragma unroll
+    for (int c = 0; c < 3; ++c)                    // in registers before the first store (else: vmcnt(0) behind each)
+      asm volatile("" : "+v"(bv[c][0]), "+v"(bv[c][1]), "+v"(bv[c][2]), "+v"(bv[c][3]));
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int col = 16 * c + li;
 #pragma unroll
@@ -1209,6 +1250,7 @@ __global__ __launch_bounds__(512) void bilinear_pairm_fwd_kernel(
     for (int j = 0; j < 4; ++j)
       bvv[j] = bm ? bm[min(16 * ti + 4 * g + j, W1 - 1) * W2 + min(col, W2 - 1)] : 0.f;
     const v4f acc = tile(ps, FB_LS, 1, as, FB_LS, 1, 16 * ti, 16 * tj);
+    asm volatile("" : "+v"(bvv[0]), "+v"(bvv[1]), "+v"(bvv[2]), "+v"(bvv[3]));   // in registers before the first store (else: vmcnt(0) behind it)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = 16 * ti + 4 * g + j;

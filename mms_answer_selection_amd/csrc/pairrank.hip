@@ -11,6 +11,7 @@
 // fixed-shape tree sum (deterministic; the reference's 1-thread running sum
 // is not reproduced -- tests hold it to 1e-5 relative).
 #include <atomic>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -26,13 +27,22 @@ int euclid_backward_mode();   // simcross_elementwise.hip
 // `ordered >= 0` (pair_rank_loss_layer.cu:51).  They differ only where margin - y*(a-b) is exactly 0.
 // Per calling thread (a Caffe host runs one thread per GPU); default: the CPU code's strict `>`.
 constexpr int kTicketSlots = 256;
-constexpr int kTicketTop = 1024;      // words 0..1023 of a ticket slot: one per group of 8 workgroups; then the top word
+constexpr int kTicketTop = 1024;      // words 0..1023 of a ticket slot: one per group of kTicketGroup workgroups; then the top word
 constexpr int kTicketStride = kTicketTop + 32;
+constexpr int kTicketGroup = 16;
+// An arrival word carries the arrivals AND what arrived, so that ONE atomic both hands over a partial loss
+// and tells its issuer whether it was the last: [63] poison, [52..62] arrivals, [0..51] sum of the terms in
+// units of 2^-S (S chosen by the host from N so that the field cannot overflow while every term < 2^kFxTermBits).
+constexpr int kFxSumBits = 52;
+constexpr int kFxTermBits = 10;
+constexpr unsigned long long kFxPoison = 1ull << 63;
+constexpr unsigned long long kFxOne = 1ull << kFxSumBits;
+constexpr unsigned long long kFxSumMask = kFxOne - 1;
 
 static thread_local int t_hinge_mode = MMS_PAIRRANK_HINGE_CPU;
 int pairrank_hinge_mode() { return t_hinge_mode; }
 void set_pairrank_hinge_mode(int m) { t_hinge_mode = m; }
-static thread_local int t_triplet_finish = MMS_TRIPLET_FINISH_LAUNCH;
+static thread_local int t_triplet_finish = MMS_TRIPLET_FINISH_INLAUNCH;
 int triplet_finish_mode() { return t_triplet_finish; }
 void set_triplet_finish_mode(int m) { t_triplet_finish = m; }
 
@@ -313,18 +323,24 @@ __global__ __launch_bounds__(256) void triplet_wave_kernel(
 // by LDS reads issued before the reductions; the stitch is the DPP OR-reduction; eight
 // waves per workgroup, no early exit, N first for the kernarg preload, streaming stores.
 // EXACT as in euclid_pair32_kernel (include/mms.h: mms_set_euclid_backward_mode).
-template <int D4C, bool EXACT, int WPB>
+template <int D4C, bool EXACT, int WPB, bool INL>
 __global__ __launch_bounds__(64 * WPB) void triplet32_kernel(
     int N, float margin, float s0, float s1, const float* __restrict__ q,
     const float* __restrict__ ap, const float* __restrict__ an, const float* __restrict__ y,
     float* __restrict__ s_pos, float* __restrict__ s_neg, float* __restrict__ partials,
     float* __restrict__ dq, float* __restrict__ dap, float* __restrict__ dan, int hinge_ge,
-    unsigned* __restrict__ ticket, float* __restrict__ loss) {
+    unsigned long long* __restrict__ ticket, float* __restrict__ loss, double fx_scale) {
   constexpr int NIT = (D4C + 63) / 64;
   constexpr int LASTN = D4C - 64 * (NIT - 1);
   constexpr int H4 = (D4C + 2) / 3, ST4 = 3 * H4;
   __shared__ float4 lds4[WPB * 2 * ST4];
+  __shared__ unsigned long long wg_arrivals;       // INL: [60..63] waves arrived, [52..59] poisoned waves, [0..51] sum
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (INL) {
+    // zeroed before anything is in flight: a raw barrier here waits for nothing but the eight wave starts
+    if (threadIdx.x == 0) wg_arrivals = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
   const int want = blockIdx.x * WPB + wave;
   const bool have = want < N;
   const int row = have ? want : N - 1;           // a wave past the end recomputes the last triplet, stores nothing
@@ -336,13 +352,13 @@ __global__ __launch_bounds__(64 * WPB) void triplet32_kernel(
   float4* sqp = lds4 + (size_t)wave * 2 * ST4;
   float4* sqn = sqp + ST4;
 
+  float yy = y[row];
   float4 x[NIT], u[NIT], v[NIT], dp[NIT], dn[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = (it < NIT - 1 || last_ok) ? lane + 64 * it : 0;
     x[it] = q4[i]; u[it] = p4[i]; v[it] = m4[i];
   }
-  const float yy = y[row];
   float pp1 = 0.f, pp2 = 0.f, pn1 = 0.f, pn2 = 0.f;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -387,15 +403,57 @@ __global__ __launch_bounds__(64 * WPB) void triplet32_kernel(
   const float Tmine = 1.0f / (1.0f + sqrtf(dist));
   const float Tp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tmine), 0));
   const float Tn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tmine), 32));
+  asm volatile("" : "+v"(yy));   // in a register before the stores below, or its wait becomes vmcnt(0) behind them (see euclid_pair32_kernel)
   if (lane == 0 && have) { s_pos[row] = Tp; s_neg[row] = Tn; }
 
   // PairRankLoss on (Tp, Tn, y): every lane computes the same scalars
   const PairTerm pt = pair_term(Tp, Tn, yy, margin);
   float ga, gb;
   pair_grad(yy, pt.ordered, pt.similar, s0, s1, ga, gb, hinge_ge != 0);
-  // the loss term leaves as a write-through (sc1) store: the launch's last workgroup sums all N of them
-  if (lane == 0 && have) __hip_atomic_store(&partials[row], pt.term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("" ::: "memory");                   // stays ahead of the streaming stores below (counted wait at the end)
+  // ---- loss scalar ------------------------------------------------------------------------------------------
+  // INL: ONE launch.  The terms are added as integers (units of 2^-S), so the sum does not depend on the order
+  // of arrival, and the arrival count travels in the same 64-bit word as the sum: an atomic's return value
+  // tells its issuer both that it was the last and what the others brought, with no store whose visibility
+  // would have to be waited for first.  Three hops: waves -> workgroup word in LDS -> one word per
+  // kTicketGroup workgroups -> top word; the wave that completes the top word writes the loss.  All of it is
+  // issued BEFORE this wave's gradient stores (one wave per workgroup waits one round trip for its group word,
+  // one per group issues the top atomic and reads its return after its stores), so the round trips run under
+  // the launch's store drain instead of behind it (the first in-launch form -- write-through term stores,
+  // arrival tickets, then a 16 KB read of the terms by the last workgroup -- had four dependent round trips
+  // behind the terms and measured 12.6 us against 11.3 for a second launch).
+  // A term outside [0, 2^kFxTermBits) (labels or a margin in the hundreds, a NaN input) poisons the words it
+  // passes through and the loss comes out NaN; the two-launch mode has no such limit (include/mms.h).
+  bool top_wait = false;
+  unsigned long long top_old = 0, top_pay = 0;
+  if (INL) {
+    if (lane == 0) {
+      const float t = have ? pt.term : 0.f;
+      const bool ok = t >= 0.f && t < (float)(1 << kFxTermBits);
+      const unsigned long long fx = ok ? (unsigned long long)((double)t * fx_scale) : 0ull;
+      const unsigned long long pay = (1ull << 60) | (ok ? 0ull : kFxOne) | fx;
+      const unsigned long long old = __hip_atomic_fetch_add(&wg_arrivals, pay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if ((old >> 60) == (unsigned long long)(WPB - 1)) {            // this wave completes the workgroup
+        const unsigned long long wg = old + pay;
+        const unsigned grp = blockIdx.x / kTicketGroup;
+        const unsigned gsize = min((unsigned)kTicketGroup, gridDim.x - (unsigned)kTicketGroup * grp);
+        const unsigned long long gpay = kFxOne | (wg & kFxSumMask);
+        if ((wg >> kFxSumBits) & 0xffull)
+          __hip_atomic_fetch_or(ticket + grp, kFxPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long gold = __hip_atomic_fetch_add(ticket + grp, gpay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (((gold >> kFxSumBits) & 0x7ffull) == (unsigned long long)(gsize - 1)) {   // ... and its group
+          const unsigned long long g = gold + gpay;
+          __hip_atomic_store(ticket + grp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the slot's next launch
+          top_pay = kFxOne | (g & kFxSumMask);
+          if (g & kFxPoison) __hip_atomic_fetch_or(ticket + kTicketTop, kFxPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          top_old = __hip_atomic_fetch_add(ticket + kTicketTop, top_pay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          top_wait = true;                                            // consumed after this wave's stores
+        }
+      }
+    }
+  } else {
+    // the term leaves as a plain store: a second, one-workgroup launch sums all N of them
+    if (lane == 0 && have) partials[row] = pt.term;
+  }
 
   float4* dq4 = reinterpret_cast<float4*>(dq) + base4;
   float4* dp4 = reinterpret_cast<float4*>(dap) + base4;
@@ -433,48 +491,14 @@ __global__ __launch_bounds__(64 * WPB) void triplet32_kernel(
     }
   }
 
-  // ---- loss scalar in the same launch (this used to be a second, one-workgroup launch: 2.3 us) -----------
-  // Hand-off of MI355X_MICROARCH.md "Valid forms": write-through term stores -> every storing wave drains its
-  // stores -> workgroup barrier -> ONE agent-scope ticket per workgroup; the workgroup whose ticket is the
-  // last reads every term with sc1 loads (never through L1) and sums them in a fixed order.
-  // only the TERM store has to be complete before the ticket: it was issued ahead of this wave's 3 * NIT
-  // streaming stores, which may still be in flight
-  if (ticket == nullptr) return;                   // the caller sums the terms with a second launch
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NIT) : "memory");
-  __shared__ unsigned last_flag;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    // two-level arrival (all workgroups finish together: 512 adds on ONE word serialise to ~6 us): groups of 8
-    // workgroups share a word, the last of a group adds to the top word
-    const unsigned grp = blockIdx.x >> 3, ngrp = (gridDim.x + 7) >> 3;
-    const unsigned gsize = min(8u, gridDim.x - 8u * grp);
-    unsigned last = 0;
-    if (__hip_atomic_fetch_add(ticket + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
-      __hip_atomic_store(ticket + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      last = __hip_atomic_fetch_add(ticket + kTicketTop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1;
-    }
-    last_flag = last;
-  }
-  __syncthreads();
-  if (!last_flag) return;
-  {
-    constexpr int TH = 64 * WPB;
-    float* red = reinterpret_cast<float*>(lds4);   // the chain images are dead
-    float sum = 0.f;
-    for (int base = threadIdx.x; base < N; base += 8 * TH) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = base + u * TH;
-        v[u] = __hip_atomic_load(&partials[i < N ? i : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) sum += (base + u * TH < N) ? v[u] : 0.f;
-    }
-    sum = block_sum<TH>(sum, red);
-    if (threadIdx.x == 0) {
-      *loss = sum / (float)N;                     // pair_rank_loss_layer.cpp:49
-      __hip_atomic_store(ticket + kTicketTop, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  if (!INL) return;
+  if (top_wait) {                                  // lane 0 of one wave per kTicketGroup workgroups
+    const unsigned ngrp = (gridDim.x + kTicketGroup - 1) / kTicketGroup;
+    if (((top_old >> kFxSumBits) & 0x7ffull) == (unsigned long long)(ngrp - 1)) {
+      const unsigned long long all = top_old + top_pay;
+      __hip_atomic_store(ticket + kTicketTop, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float sum = (float)((double)(all & kFxSumMask) / fx_scale);
+      *loss = (all & kFxPoison) ? __builtin_nanf("") : sum / (float)N;                       // pair_rank_loss_layer.cpp:49
     }
   }
 }
@@ -556,17 +580,17 @@ constexpr int kTripThreads = 256;
 // zeroes them; the launch's last workgroup resets its slot), and consecutive calls take consecutive slots, so
 // launches in flight together -- other streams, other captured graphs -- never share one (a slot comes round
 // again after kTicketSlots calls).
-__device__ unsigned g_triplet_tickets[kTicketSlots * kTicketStride];
-static unsigned* next_ticket_slot() {
+__device__ unsigned long long g_triplet_tickets[kTicketSlots * kTicketStride];
+static unsigned long long* next_ticket_slot() {
   static std::atomic<unsigned> next{0};
-  static thread_local unsigned* base = nullptr;    // device address of the array on this thread's current device
+  static thread_local unsigned long long* base = nullptr;    // device address of the array on this thread's current device
   static thread_local int base_dev = -1;
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   if (base == nullptr || dev != base_dev) {
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_triplet_tickets)) != hipSuccess) return nullptr;
-    base = static_cast<unsigned*>(p);
+    base = static_cast<unsigned long long*>(p);
     base_dev = dev;
   }
   return base + (size_t)(next.fetch_add(1, std::memory_order_relaxed) % kTicketSlots) * kTicketStride;
@@ -593,25 +617,26 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
     nparts = N;
     const unsigned grid = (unsigned)((N + WPB - 1) / WPB);
     const bool exact = euclid_backward_mode() == MMS_EUCLID_BWD_REFERENCE;
-#define MMS_T32(d4)                                                                               \
-  case 4 * d4:                                                                                    \
-    if (exact)                                                                                    \
-      hipLaunchKernelGGL((triplet32_kernel<d4, true, WPB>), dim3(grid), dim3(64 * WPB), 0, s, N,  \
-                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan, hge, \
-                         tk, loss);                                                               \
-    else                                                                                          \
-      hipLaunchKernelGGL((triplet32_kernel<d4, false, WPB>), dim3(grid), dim3(64 * WPB), 0, s, N, \
-                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan, hge, \
-                         tk, loss);                                                               \
+#define MMS_T32_GO(d4, ex, inl)                                                                        \
+  hipLaunchKernelGGL((triplet32_kernel<d4, ex, WPB, inl>), dim3(grid), dim3(64 * WPB), 0, s, N, margin,  \
+                     s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan, hge, tk, loss, fx_scale)
+#define MMS_T32(d4)                                                       \
+  case 4 * d4:                                                            \
+    if (exact) { if (tk) MMS_T32_GO(d4, true, true); else MMS_T32_GO(d4, true, false); }     \
+    else       { if (tk) MMS_T32_GO(d4, false, true); else MMS_T32_GO(d4, false, false); }   \
     break;
-    // Default: the loss terms are summed by a second, one-workgroup launch.  The in-launch form (last workgroup
-    // sums, mms_set_triplet_finish_mode) was built and measured SLOWER on MI355X: 12.6 vs 11.3 us per 4096 x 300
-    // step HBM-cold -- the write-through term store's acknowledgement, two ticket round trips and the 16 KB read
-    // of the terms form a serial tail of ~4 us behind the last store, the kernel boundary + finish launch 3.5.
-    unsigned* tk = (triplet_finish_mode() != MMS_TRIPLET_FINISH_INLAUNCH || (grid + 7) / 8 > (unsigned)kTicketTop)
-                       ? nullptr : next_ticket_slot();
+    // MMS_TRIPLET_FINISH_INLAUNCH: the loss is summed inside the launch (integer terms, arrival words that carry
+    // the sum: see the kernel); otherwise, and for batches beyond what a ticket slot covers, the per-triplet
+    // terms are summed by a second, one-workgroup launch.
+    const unsigned ngrp = (grid + kTicketGroup - 1) / kTicketGroup;
+    unsigned long long* tk = (triplet_finish_mode() != MMS_TRIPLET_FINISH_INLAUNCH || ngrp > (unsigned)kTicketTop)
+                                 ? nullptr : next_ticket_slot();
+    int lg = 0;
+    while (((long long)1 << lg) < (long long)N) ++lg;
+    const double fx_scale = std::ldexp(1.0, kFxSumBits - kFxTermBits - lg);
     switch (D) { MMS_T32(25) MMS_T32(50) MMS_T32(75) }
 #undef MMS_T32
+#undef MMS_T32_GO
     if (tk) return launch_status();               // the loss was reduced inside the launch
   } else if (v && D <= 1024) {
     const int D4 = D / 4;

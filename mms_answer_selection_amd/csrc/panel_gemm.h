@@ -348,21 +348,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       ik0 += 32;
       if (ik0 >= kend) { ik0 = kbeg; ++iseg; }
     };
-    // side job: rows g + 4 rr of this wave's 16-row block, one rr per iteration: loaded in iteration rr,
-    // scaled and stored in iteration rr + 1
+    // side job: rows g + 4 rr of this wave's 16-row block, one rr per iteration: requested in iteration rr,
+    // scaled and stored in iteration rr + 1.
+    // Its loads are issued by hand (asm), like the DMAs: the compiler does not see the DMAs, so for a load it
+    // does see it counts no younger operation and waits with vmcnt(<= 4) at the first use -- i.e. until the
+    // tile requested a moment ago has landed.  That cost one tile of prefetch distance in each of the first
+    // four iterations of every workgroup.  Requested by hand, side-job data is covered by the loop's own counted
+    // wait (it is issued BEFORE the DMAs of its iteration: vmcnt(NPT) at the top of the next one means it has
+    // landed); side_pin() then hands the registers to the compiler, and nothing may read them before it.
     const int SC = p.side_in ? p.side_cols >> 2 : 0;
     pg_v4f sx[NCC];
+    float ssc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.side_in) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float* src = p.side_scale + min(i0 + g + 4 * rr, p.M - 1);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(ssc[rr]) : "v"(src) : "memory");
+      }
+    }
     auto side_load = [&](int rr) {
       const int growc = min(i0 + g + 4 * rr, p.M - 1);
 #pragma unroll
       for (int cc = 0; cc < NCC; ++cc) {
         const int c4 = r + 16 * cc;
-        sx[cc] = *reinterpret_cast<const pg_v4f*>(p.side_in + (long long)growc * p.side_ld + 4 * (c4 < SC ? c4 : 0));
+        const float* src = p.side_in + (long long)growc * p.side_ld + 4 * (c4 < SC ? c4 : 0);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sx[cc]) : "v"(src) : "memory");
       }
+    };
+    auto side_pin = [&]() {                            // only behind a wait that covers the requests above
+#pragma unroll
+      for (int cc = 0; cc < NCC; ++cc) asm volatile("" : "+v"(sx[cc]));
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) asm volatile("" : "+v"(ssc[rr]));
     };
     auto side_store = [&](int rr) {
       const int grow = i0 + g + 4 * rr;
-      const float sc = p.side_scale[min(grow, p.M - 1)];
+      const float sc = ssc[rr];
 #pragma unroll
       for (int cc = 0; cc < NCC; ++cc) {
         const int c4 = r + 16 * cc;
@@ -389,7 +410,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPT) : "memory");       // B_T
 #endif
       if (p.side_in) {
-        if (T >= 1 && T <= 4) side_store(T - 1);
+        if (T >= 1 && T <= 4) { side_pin(); side_store(T - 1); }
         if (T < 4) side_load(T);
       }
 #if defined(MMS_PG_ABLATE) && MMS_PG_ABLATE >= 1      // dev-only timing ablation (tools/panelbench.hip): no loads after the prologue
@@ -410,9 +431,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (p.side_in) {                                  // what the loop was too short for
       const int done_load = ntiles < 4 ? ntiles : 4;
       const int done_store = (ntiles < 5 ? ntiles : 5) > 0 ? (ntiles < 5 ? ntiles : 5) - 1 : 0;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      side_pin();
       if (done_store < done_load) side_store(done_load - 1);
       for (int rr = done_load; rr < 4; ++rr) {
         side_load(rr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        side_pin();
         side_store(rr);
       }
     }
@@ -472,14 +497,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const bool do_dot = loader && p.Y;
   const bool do_store = Cg && (p.Y ? !loader : true);
   const int rr0 = p.Y ? 0 : (loader ? 2 : 0), rr1 = p.Y ? 4 : (loader ? 4 : 2);
+  // every scalar the pass needs is in a register before its first store: the stores sit under lane masks, so a
+  // load consumed after one became s_waitcnt vmcnt(0) -- a wait for the ACKNOWLEDGEMENT of the row group just
+  // stored, four times per workgroup
+  float rsv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+  if (p.rowscale) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) rsv[rr] = p.rowscale[min(i0 + g + 4 * rr, p.M - 1)];
+  }
+  float rdb = (do_dot && p.rd_bias) ? p.rd_bias[bt] : 0.f;
+  asm volatile("" : "+v"(rsv[0]), "+v"(rsv[1]), "+v"(rsv[2]), "+v"(rsv[3]), "+v"(rdb));
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     if (rr < rr0 || rr >= rr1) continue;
     if (!do_dot && !do_store) continue;
     const int row_l = g + 4 * rr, grow = i0 + row_l;
     const bool valid = grow < p.M;
-    const int growc = valid ? grow : p.M - 1;
-    const float rs = p.rowscale ? p.rowscale[growc] : 1.0f;
+    const float rs = rsv[rr];
     float dot = 0.f;
 #pragma unroll
     for (int cc = 0; cc < NCC; ++cc) {
@@ -506,7 +540,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       dot = dpp_add<0x140, 0xf>(dot);
       if (r == 0 && valid) {
         float* out = p.rowdot + (long long)bt * p.rd_b + (long long)grow * p.rd_stride;
-        *out = p.rd_bias ? (p.rd_bias[bt] + dot) : dot;
+        *out = p.rd_bias ? (rdb + dot) : dot;
       }
     }
   }

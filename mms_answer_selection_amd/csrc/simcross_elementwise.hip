@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_kernel(
 #endif
     MMS_STAMP(4);
     T = 1.0f / (1.0f + sqrtf(dist));            // :106-107
+    if (BWD) asm volatile("" : "+v"(g));        // in a register before the store of T (see euclid_pair32_kernel)
     if (j == 0 && grp < rows) top_out[row0 + grp] = T;
   }
   if (!BWD) return;
@@ -249,6 +250,10 @@ __global__ __launch_bounds__(64 * WPB) void euclid_pair32_kernel(
   const bool last_ok = (LASTN >= 32) || (j < LASTN);
 
   MMS_STAMP(0);
+  float T = 0.f;
+  if (!FWD) T = top_in[row];
+  float g = 0.f;
+  if (BWD) g = top_diff[row];
   float4 x[NIT], y[NIT], df[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -257,10 +262,6 @@ __global__ __launch_bounds__(64 * WPB) void euclid_pair32_kernel(
     y[it] = a4[i];
   }
   MMS_STAMP(1);
-  float T = 0.f;
-  if (!FWD) T = top_in[row];
-  float g = 0.f;
-  if (BWD) g = top_diff[row];
 
   float p1 = 0.f, p2 = 0.f;
   float4* img = lds4 + (wave * 2 + grp) * ST4;
@@ -318,12 +319,22 @@ __global__ __launch_bounds__(64 * WPB) void euclid_pair32_kernel(
 #else
     T = 1.0f / (1.0f + sqrtf(dist));            // :106-107
 #endif
+    // g is pinned as "in a register" HERE, before the store of T: left to the compiler, its first use came
+    // after that store (issued under a lane mask, so the wait could not be counted) and every wave sat in
+    // s_waitcnt vmcnt(0) until the store was acknowledged
+    if (BWD) asm volatile("" : "+v"(g));
     if (j == 0 && have) top_out[row] = T;
   }
   if (!BWD) return;
 
   float4* dq4 = reinterpret_cast<float4*>(dq) + (size_t)row * D4C;
   float4* da4 = reinterpret_cast<float4*>(da) + (size_t)row * D4C;
+  if (!FWD) {                                   // all requests landed before the first store (see euclid_block_kernel)
+    asm volatile("" : "+v"(T), "+v"(g));
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      asm volatile("" : "+v"(df[it].x), "+v"(df[it].y), "+v"(df[it].z), "+v"(df[it].w));
+  }
   float4 t[NIT];
   if (EXACT) {
     const EuclidCoef k = euclid_coef(T, g);
@@ -482,6 +493,10 @@ __global__ __launch_bounds__(64 * WPB) void euclid_block_kernel(
     }
     __builtin_amdgcn_s_setprio(0);
     const float Tp = 1.0f / (1.0f + sqrtf(dist));            // :106-107
+    if (BWD) {                                  // in registers before the store of T (see euclid_pair32_kernel)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(gg[it]));
+    }
     if (j == 0) {
       if (have) top_out[row] = Tp;
       if (BWD) Tl[lp] = Tp;
@@ -492,6 +507,17 @@ __global__ __launch_bounds__(64 * WPB) void euclid_block_kernel(
 
   float4* dq4 = reinterpret_cast<float4*>(dq);
   float4* da4 = reinterpret_cast<float4*>(da);
+  if (!FWD) {
+    // Everything this thread requested is in registers before its first store.  The stores sit under lane masks
+    // (the end of the batch), so the compiler cannot count them: a load consumed after a store became
+    // s_waitcnt vmcnt(0), i.e. a wait for the ACKNOWLEDGEMENT of the stores already issued -- in the middle of
+    // the store phase of the launch that bounds the headline.
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      asm volatile("" : "+v"(gg[it]), "+v"(Tg[it]));
+      asm volatile("" : "+v"(df[it].x), "+v"(df[it].y), "+v"(df[it].z), "+v"(df[it].w));
+    }
+  }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = tid + T * it;
@@ -627,6 +653,7 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_f16_kernel(
                           : chain_sum_speculative<LPR>(sq4 + grow * st4, D4, my1, my2, j, grp * LPR);
 #endif
   const float T = 1.0f / (1.0f + sqrtf(dist));
+  if (BWD) asm volatile("" : "+v"(g));          // in a register before the store of T (see euclid_pair32_kernel)
   if (j == 0 && grp < rows) top_out[row0 + grp] = T;
   if (!BWD) return;
 
@@ -830,6 +857,8 @@ __global__ __launch_bounds__(256) void cosine_rows_kernel(
   if (row >= N) return;
   const float* qr = q + (size_t)row * D;
   const float* ar = a + (size_t)row * D;
+  float g = 0.f;
+  if (BWD) g = top_diff[row];                    // requested up front; pinned before the stores of the forward
   float T, n0, n1;
   if (FWD) {
     float sqq = 0.f, saa = 0.f, sqa = 0.f;
@@ -852,12 +881,12 @@ __global__ __launch_bounds__(256) void cosine_rows_kernel(
     n0 = sqrtf(sqq);
     n1 = sqrtf(saa);
     T = sqa / n0 / n1;  // two successive divisions (:135)
+    if (BWD) asm volatile("" : "+v"(g));
     if (lane == 0) { top[row] = T; norm0[row] = n0; norm1[row] = n1; }
   } else {
     T = top[row]; n0 = norm0[row]; n1 = norm1[row];
   }
   if (!BWD) return;
-  const float g = top_diff[row];
   float* dqr = dq + (size_t)row * D;
   float* dar = da + (size_t)row * D;
   // :239-245   dq += g*(a/n0/n1 - q*T/(n0*n0)) ; da += g*(q/n0/n1 - a*T/(n1*n1))
@@ -1078,6 +1107,19 @@ struct CrossAcc {
   __device__ __forceinline__ void finish(float* __restrict__ top, const float* __restrict__ norm0,
                                          const float* __restrict__ norm1, int n, int j0, int k0,
                                          int lj, int lk, int W1, int W2) const {
+    // cosine: this lane's RJ + RK norms are in registers before its first store (a load between two stores
+    // waits, with vmcnt(0), for the acknowledgement of the store in front of it)
+    float n0v[RJ], n1v[RK];
+    if (MODE != 1) {
+#pragma unroll
+      for (int x = 0; x < RJ; ++x) n0v[x] = norm0[(size_t)n * W1 + min(j0 + lj + 8 * x, W1 - 1)];
+#pragma unroll
+      for (int y = 0; y < RK; ++y) n1v[y] = norm1[(size_t)n * W2 + min(k0 + lk + 8 * y, W2 - 1)];
+#pragma unroll
+      for (int x = 0; x < RJ; ++x) asm volatile("" : "+v"(n0v[x]));
+#pragma unroll
+      for (int y = 0; y < RK; ++y) asm volatile("" : "+v"(n1v[y]));
+    }
 #pragma unroll
     for (int x = 0; x < RJ; ++x) {
       const int j = j0 + lj + 8 * x;
@@ -1095,7 +1137,7 @@ struct CrossAcc {
         if (MODE == 1) {
           T = 1.0f / (1.0f + sqrtf(get(x, y)));
         } else {
-          T = get(x, y) / norm0[(size_t)n * W1 + j] / norm1[(size_t)n * W2 + k];
+          T = get(x, y) / n0v[x] / n1v[y];
         }
 #if defined(MMS_XABL) && MMS_XABL == 3   // dev-only timing ablation: no stores
         if (T != T + 1.0f && T == 12345.678f)

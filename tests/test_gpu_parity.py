@@ -572,9 +572,9 @@ def test_pairrank_hinge_comparison_modes(oracle, hiplib):
 
 
 def test_triplet_step_many_launches_and_graph_replay(hiplib):
-    """The loss of the fused step is reduced inside the launch by its last workgroup through an arrival ticket
-    that the launch hands back zeroed: thousands of launches (more than there are ticket slots) and replays of
-    one captured graph must all return the first launch's bits."""
+    """The loss of the fused step is summed inside the launch through arrival words that the launch hands back
+    zeroed: thousands of launches (more than there are ticket slots) and replays of one captured graph must all
+    return the first launch's bits."""
     from mms_answer_selection_amd import capi
     N, D = 4096, 300
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -586,13 +586,64 @@ def test_triplet_step_many_launches_and_graph_replay(hiplib):
                       dq=nan_like(q.shape), da_pos=nan_like(q.shape), da_neg=nan_like(q.shape))
     ws = capi.Workspace()
     two = mk()
-    capi.triplet_euclid_step(q, ap, an, y, margin=0.05, ws=ws, **two)      # default: loss summed by a second launch
-    first = mk()
-    capi.set_triplet_finish_mode("inlaunch")
+    capi.set_triplet_finish_mode("launch")
     try:
-        _many_launches(capi, q, ap, an, y, ws, mk, first, two)
+        capi.triplet_euclid_step(q, ap, an, y, margin=0.05, ws=ws, **two)      # loss summed by a second launch
     finally:
-        capi.set_triplet_finish_mode("launch")
+        capi.set_triplet_finish_mode("inlaunch")                               # the default
+    first = mk()
+    _many_launches(capi, q, ap, an, y, ws, mk, first, two)
+
+
+def test_triplet_step_inlaunch_loss_domain(hiplib):
+    """In-launch mode sums the terms as integers in units of 2^-S: a term of 2^10 or more (a margin or labels in
+    the hundreds) cannot be carried and the loss must come out NaN, not wrong; scores and gradients are
+    unaffected, the two-launch mode has no such limit, and a batch beyond what a ticket slot covers falls back
+    to the second launch by itself."""
+    from mms_answer_selection_amd import capi
+    N, D = 520, 300
+    g = torch.Generator(device="cuda").manual_seed(11)
+    q = torch.randn(N, 1, D, device="cuda", generator=g) * 0.4
+    ap = q + 0.1 * torch.randn(N, 1, D, device="cuda", generator=g)
+    an = torch.randn(N, 1, D, device="cuda", generator=g) * 0.4
+    y = torch.ones(N, 1, device="cuda")
+    mk = lambda n=N: dict(s_pos=nan_like((n, 1)), s_neg=nan_like((n, 1)), loss=nan_like((1,)),
+                          dq=nan_like((n, 1, D)), da_pos=nan_like((n, 1, D)), da_neg=nan_like((n, 1, D)))
+    big, ref = mk(), mk()
+    capi.triplet_euclid_step(q, ap, an, y, margin=5000.0, **big)
+    capi.set_triplet_finish_mode("launch")
+    try:
+        capi.triplet_euclid_step(q, ap, an, y, margin=5000.0, **ref)
+    finally:
+        capi.set_triplet_finish_mode("inlaunch")
+    assert np.isnan(host(big["loss"])[0])
+    assert np.isfinite(host(ref["loss"])[0]) and host(ref["loss"])[0] > 4000
+    assert_bitexact(host(big["dq"]), host(ref["dq"]))
+    assert_bitexact(host(big["s_pos"]), host(ref["s_pos"]))
+    # the words are handed back clean: the next in-domain launch is unaffected
+    ok = mk()
+    capi.triplet_euclid_step(q, ap, an, y, margin=0.05, **ok)
+    capi.set_triplet_finish_mode("launch")
+    try:
+        capi.triplet_euclid_step(q, ap, an, y, margin=0.05, **ref)
+    finally:
+        capi.set_triplet_finish_mode("inlaunch")
+    assert_close(host(ok["loss"])[0], host(ref["loss"])[0], TOL, "after a poisoned launch")
+    # a term just inside the domain
+    edge = mk()
+    capi.triplet_euclid_step(q, ap, an, y, margin=1022.0, **edge)
+    assert abs(host(edge["loss"])[0] - 1022.0) < 1.5
+    # beyond a slot (131072 triplets): second launch, same entry point
+    n2 = 131072 + 24
+    q2 = torch.randn(n2, 1, 100, device="cuda", generator=g) * 0.4
+    a2 = torch.randn(n2, 1, 100, device="cuda", generator=g) * 0.4
+    y2 = torch.ones(n2, 1, device="cuda")
+    o1 = dict(s_pos=nan_like((n2, 1)), s_neg=nan_like((n2, 1)), loss=nan_like((1,)),
+              dq=nan_like(q2.shape), da_pos=nan_like(q2.shape), da_neg=nan_like(q2.shape))
+    capi.triplet_euclid_step(q2, q2 + 0.05 * a2, a2, y2, margin=0.05, **o1)
+    sp, sn = host(o1["s_pos"]).astype(np.float64), host(o1["s_neg"]).astype(np.float64)
+    want = np.maximum(0.0, 0.05 - (sp - sn)).mean()
+    assert_close(host(o1["loss"])[0], want, TOL, "loss of a batch beyond one slot")
 
 
 def _many_launches(capi, q, ap, an, y, ws, mk, first, two):
@@ -630,7 +681,8 @@ def _many_launches(capi, q, ap, an, y, ws, mk, first, two):
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("cfg", [(8, 300), (4096, 300), (4091, 300), (1, 300), (77, 301), (5, 4), (19, 1024), (7, 400),
                                  (33, 200), (9, 100), (1000, 100)])
-def test_triplet_step(cfg, oracle, hiplib):
+@pytest.mark.parametrize("finish", ["inlaunch", "launch"])
+def test_triplet_step(cfg, finish, oracle, hiplib):
     from mms_answer_selection_amd import capi
     N, D = cfg
     margin, lw = 0.05, 1.0
@@ -649,7 +701,11 @@ def test_triplet_step(cfg, oracle, hiplib):
 
     out = dict(s_pos=nan_like((N, 1)), s_neg=nan_like((N, 1)), loss=nan_like((1,)),
                dq=nan_like(q.shape), da_pos=nan_like(q.shape), da_neg=nan_like(q.shape))
-    capi.triplet_euclid_step(dev(q), dev(ap), dev(an), dev(y), margin=margin, loss_weight=lw, **out)
+    capi.set_triplet_finish_mode(finish)
+    try:
+        capi.triplet_euclid_step(dev(q), dev(ap), dev(an), dev(y), margin=margin, loss_weight=lw, **out)
+    finally:
+        capi.set_triplet_finish_mode("inlaunch")
     assert_bitexact(host(out["s_pos"]).ravel(), sp.ravel(), "s_pos")
     assert_bitexact(host(out["s_neg"]).ravel(), sn.ravel(), "s_neg")
     assert_close(host(out["loss"])[0], loss_ref, TOL, "loss")

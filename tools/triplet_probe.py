@@ -3,6 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mms_answer_selection_amd import capi
+mode = sys.argv[1] if len(sys.argv) > 1 else "launch"
+capi.set_triplet_finish_mode(mode)
 N, D, ring, G = 4096, 300, 48, 16
 g = torch.Generator(device="cuda").manual_seed(1)
 mk = lambda *s: torch.randn(*s, device="cuda", generator=g) * 0.4
@@ -33,4 +35,4 @@ for rep in range(7):
     e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1) * 1e3 / (12 * G))
 ts.sort()
-print("triplet step %s: median %.2f us  min %.2f" % (os.environ.get("MMS_TRIPLET_FINISH", "in-launch"), ts[len(ts) // 2], ts[0]))
+print("triplet step %s: median %.2f us  min %.2f   loss %r" % (mode, ts[len(ts) // 2], ts[0], loss[:3, 0].tolist()))
