@@ -256,6 +256,30 @@ __global__ __launch_bounds__(256) void gemm64_kernel(G64 g) {
   double* C = g.C + b0 * g.c_b0 + b1 * g.c_b1;
   const double* rs = g.rowscale ? g.rowscale + b0 * g.rs_b0 : nullptr;
   const double* bias = g.bias ? g.bias + b1 * g.bias_b1 : nullptr;
+  // what the epilogue reads is in registers before its first store (clamped addresses keep the loads
+  // unconditional): element by element, each load waited with vmcnt(0) for the store in front of it
+  double rsv[2][4], bsv[2][2][4], cvv[2][2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const i64 mc = min(m0 + wm + 16 * i + 4 * r + lg, g.M - 1);
+      rsv[i][r] = rs ? rs[mc] : 1.0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const i64 nc = min(n0 + wn + 16 * j + li, g.N - 1);
+        bsv[i][j][r] = bias ? bias[mc * g.ldbias + nc] : 0.0;
+        cvv[i][j][r] = g.beta ? C[mc * g.ldc + nc] : 0.0;
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      asm volatile("" : "+v"(rsv[i][r]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(bsv[i][j][r]), "+v"(cvv[i][j][r]));
+    }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -267,10 +291,10 @@ __global__ __launch_bounds__(256) void gemm64_kernel(G64 g) {
         const int m = m0 + wm + 16 * i + 4 * r + lg, n = n0 + wn + 16 * j + li;
         if (m < g.M && n < g.N) {
           double v = acc[i][j][r];
-          if (rs) v = rs[m] * v;
-          if (bias) v = bias[(i64)m * g.ldbias + n] + v;
+          if (rs) v = rsv[i][r] * v;
+          if (bias) v = bsv[i][j][r] + v;
           double* c = C + (i64)m * g.ldc + n;
-          *c = g.beta ? *c + v : v;
+          *c = g.beta ? cvv[i][j][r] + v : v;
         }
       }
 }

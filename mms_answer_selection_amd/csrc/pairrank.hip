@@ -154,6 +154,10 @@ __global__ __launch_bounds__(kSmallThreads) void pairrank_fwd_small_kernel(
     const int ii = i < count ? i : 0;
     va[u] = a[ii]; vb[u] = b[ii]; vy[u] = y[ii];
   }
+  // all 24 values in registers before the first store: the stores sit under `i < count`, so the compiler cannot
+  // count them and the wait for the NEXT value became vmcnt(0) -- the acknowledgement of the stores just issued
+#pragma unroll
+  for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(va[u]), "+v"(vb[u]), "+v"(vy[u]));
   float s = 0.f;
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
