@@ -568,6 +568,30 @@ static bool gemm_launch_group(const GemmArgs* gs, const int* nb0s, int n, hipStr
   return true;
 }
 
+// s + part[0*n + e] + part[1*n + e] + ... in s-ascending order (the reference accumulates over pairs / measures in
+// that order).  All requests of a batch are in flight before the first add -- a load-add-load loop costs one
+// memory round trip per slab; batches of 32 above eight slabs (a training batch of 50 pairs: two round trips
+// instead of seven), of 8 below (dQ / dA over four measures: no wasted requests).
+__device__ __forceinline__ float ordered_slab_sum(const float* __restrict__ part, long long n, long long e, int splits,
+                                                  float s) {
+  if (splits > 8) {
+    for (int k0 = 0; k0 < splits; k0 += 32) {
+      float v[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) v[u] = part[(long long)min(k0 + u, splits - 1) * n + e];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) s += (k0 + u < splits) ? v[u] : 0.f;
+    }
+    return s;
+  }
+  float v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v[u] = part[(long long)min(u, splits - 1) * n + e];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s += (u < splits) ? v[u] : 0.f;
+  return s;
+}
+
 // Several split-K reductions in one launch: problem p owns blocks [first[p], first[p+1]).
 struct ReduceGroup {
   const float* part[kGroupMax];
@@ -590,15 +614,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroup rg
   const long long stride = (long long)(rg.first[p + 1] - rg.first[p]) * 256;
   const bool accumulate = rg.accumulate[p] != 0;
   for (long long e = (long long)(blockIdx.x - rg.first[p]) * 256 + threadIdx.x; e < n; e += stride) {
-    float s = accumulate ? out[e] : 0.f;
-    for (int k0 = 0; k0 < splits; k0 += 8) {     // same order and batching as splitk_reduce_kernel
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = part[(long long)min(k0 + u, splits - 1) * n + e];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += (k0 + u < splits) ? v[u] : 0.f;
-    }
-    out[e] = s;
+    out[e] = ordered_slab_sum(part, n, e, splits, accumulate ? out[e] : 0.f);
   }
 }
 
@@ -609,16 +625,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             int accumulate) {
   const long long stride = (long long)gridDim.x * 256;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
-    float s = 0.f;
-    // eight slabs requested before the first add (same s-ascending order; a load-add-load loop
-    // costs one memory round trip per slab)
-    for (int k0 = 0; k0 < splits; k0 += 8) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = part[(long long)min(k0 + u, splits - 1) * n + e];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += (k0 + u < splits) ? v[u] : 0.f;
-    }
+    const float s = ordered_slab_sum(part, n, e, splits, 0.f);
     out[e] = accumulate ? out[e] + s : s;
   }
 }
@@ -634,14 +641,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_transpose_kernel(const floa
   if ((int)blockIdx.x < red_blocks) {
     const long long stride = (long long)red_blocks * 256;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
-      float s = 0.f;
-      for (int k0 = 0; k0 < splits; k0 += 8) {       // same s-ascending order as splitk_reduce_kernel
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = part[(long long)min(k0 + u, splits - 1) * n + e];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += (k0 + u < splits) ? v[u] : 0.f;
-      }
+      const float s = ordered_slab_sum(part, n, e, splits, 0.f);
       out[e] = accumulate ? out[e] + s : s;
     }
     return;

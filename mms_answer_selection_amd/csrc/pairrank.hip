@@ -507,6 +507,211 @@ __global__ __launch_bounds__(64 * WPB) void triplet32_kernel(
   }
 }
 
+// ---- the same step with TWO triplets per wave --------------------------------------------------------------
+// A wave owns triplets 2w and 2w+1: their rows of q, a+ and a- are ONE dense run of 2*D4C float4 per array
+// (lane l holds float4s l, l+64, l+128 of the run, whatever triplet they fall in), all requested up front.
+// The two triplets then go through the chain phase one after the other -- pass 0, pass 1, each exactly the
+// half-wave scheme of triplet32_kernel on images in LDS -- and a pass stores its own triplet's gradients as
+// soon as its scores are known: pass 1's LDS round trip and packed-add chains run while pass 0's stores drain,
+// instead of every wave of the launch chaining and then every wave storing.  Half as many waves to dispatch,
+// and a CU has half as many chains in its LDS return path at a time.  Same arithmetic, same bits.
+template <int D4C, bool EXACT, int WPB, bool INL>
+__global__ __launch_bounds__(64 * WPB) void triplet32x2_kernel(
+    int N, float margin, float s0, float s1, const float* __restrict__ q,
+    const float* __restrict__ ap, const float* __restrict__ an, const float* __restrict__ y,
+    float* __restrict__ s_pos, float* __restrict__ s_neg, float* __restrict__ partials,
+    float* __restrict__ dq, float* __restrict__ dap, float* __restrict__ dan, int hinge_ge,
+    unsigned long long* __restrict__ ticket, float* __restrict__ loss, double fx_scale) {
+  constexpr int C = 2 * D4C;                       // float4 per array per wave
+  constexpr int NIT = (C + 63) / 64;
+  constexpr int PNIT = (D4C + 31) / 32, LASTN = D4C - 32 * (PNIT - 1);
+  constexpr int H4 = (D4C + 2) / 3, ST4 = 3 * H4;
+  __shared__ float4 lds4[WPB * 4 * ST4];           // per wave: (triplet 0, +), (0, -), (1, +), (1, -)
+  __shared__ unsigned long long wg_arrivals;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (INL) {
+    if (threadIdx.x == 0) wg_arrivals = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  const long long r0 = ((long long)blockIdx.x * WPB + wave) * 2;
+  const long long total4 = (long long)N * D4C;
+  const long long b4 = r0 * D4C;
+  const float4* q4 = reinterpret_cast<const float4*>(q);
+  const float4* p4 = reinterpret_cast<const float4*>(ap);
+  const float4* m4 = reinterpret_cast<const float4*>(an);
+  float yy[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) yy[t] = y[min(r0 + t, (long long)N - 1)];
+  float4 dp[NIT], dn[NIT];
+  {
+    float4 x[NIT], u[NIT], v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = lane + 64 * it;
+      long long gi = b4 + ((NIT * 64 == C || i < C) ? i : 0);          // clamp: keep the load unconditional
+      gi = gi < total4 ? gi : total4 - 1;                              // a run past the end reads the last float4
+      x[it] = q4[gi]; u[it] = p4[gi]; v[it] = m4[gi];
+    }
+    float4* img = lds4 + (size_t)wave * 4 * ST4;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = lane + 64 * it;
+      dp[it].x = x[it].x - u[it].x; dp[it].y = x[it].y - u[it].y;
+      dp[it].z = x[it].z - u[it].z; dp[it].w = x[it].w - u[it].w;
+      dn[it].x = x[it].x - v[it].x; dn[it].y = x[it].y - v[it].y;
+      dn[it].z = x[it].z - v[it].z; dn[it].w = x[it].w - v[it].w;
+      float4 a, b;
+      a.x = dp[it].x * dp[it].x; a.y = dp[it].y * dp[it].y;
+      a.z = dp[it].z * dp[it].z; a.w = dp[it].w * dp[it].w;
+      b.x = dn[it].x * dn[it].x; b.y = dn[it].y * dn[it].y;
+      b.z = dn[it].z * dn[it].z; b.w = dn[it].w * dn[it].w;
+      if (NIT * 64 == C || i < C) {
+        const int t = i >= D4C ? 1 : 0, c = i - t * D4C;
+        img[(2 * t) * ST4 + c] = a;
+        img[(2 * t + 1) * ST4 + c] = b;
+      }
+    }
+    if constexpr (ST4 > D4C) {                                         // zero tail of each of the four images
+      if (lane < 4 * (ST4 - D4C))
+        img[(lane / (ST4 - D4C)) * ST4 + D4C + lane % (ST4 - D4C)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  asm volatile("" : "+v"(yy[0]), "+v"(yy[1]));    // in registers before any store (see euclid_pair32_kernel)
+  wave_lds_sync();
+
+  const int br = lane >> 5, j = lane & 31;         // branch walked by this half-wave
+  float4* dq4 = reinterpret_cast<float4*>(dq);
+  float4* dp4 = reinterpret_cast<float4*>(dap);
+  float4* dn4 = reinterpret_cast<float4*>(dan);
+  // In-launch loss: both passes first, then the arrival atomics, then ALL gradient stores, so that the atomics
+  // enter the memory queues ahead of the wave's 7 KB of stores.  Measured (rocprofv3): the launch takes 9.6 us
+  // with the in-launch sum against 7.6 us without, wherever the atomics are issued -- two DEPENDENT device-scope
+  // atomic round trips (group word, then top word; they execute at the memory side of the fabric, not in an
+  // XCD's L2) cost ~1.9 us, about what the second launch costs (1.9-2.3 us): 10.0 vs 10.2 us per step.
+  // With the second launch a pass stores as soon as its scores are known.
+  constexpr bool LATE = INL;
+  unsigned long long fx_sum = 0, fx_bad = 0;
+  bool top_wait = false;
+  unsigned long long top_old = 0, top_pay = 0;
+  EuclidCoef k0[2], k1[2];
+  float c0[2] = {0.f, 0.f}, c1[2] = {0.f, 0.f}, rr0[2] = {0.f, 0.f}, rr1[2] = {0.f, 0.f};
+  auto store_pass = [&](int t) {                   // gradients of triplet t's float4s (a slot can hold both triplets': masked)
+    const bool have = r0 + t < N;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (64 * it >= (t + 1) * D4C || 64 * it + 63 < t * D4C) continue;   // no float4 of triplet t in this slot
+      const int i = lane + 64 * it;
+      const bool mine = have && i >= t * D4C && i < (t + 1) * D4C;
+      float4 tp, tn;
+      if (EXACT) { tp = euclid_tt4(k0[t], dp[it]); tn = euclid_tt4(k1[t], dn[it]); }
+      else {
+        tp.x = (c0[t] * dp[it].x) * rr0[t]; tp.y = (c0[t] * dp[it].y) * rr0[t];
+        tp.z = (c0[t] * dp[it].z) * rr0[t]; tp.w = (c0[t] * dp[it].w) * rr0[t];
+        tn.x = (c1[t] * dn[it].x) * rr1[t]; tn.y = (c1[t] * dn[it].y) * rr1[t];
+        tn.z = (c1[t] * dn[it].z) * rr1[t]; tn.w = (c1[t] * dn[it].w) * rr1[t];
+      }
+      if (mine) {
+        float4 oq, op, on;
+        oq.x = (0.f + tp.x) + (0.f + tn.x); oq.y = (0.f + tp.y) + (0.f + tn.y);
+        oq.z = (0.f + tp.z) + (0.f + tn.z); oq.w = (0.f + tp.w) + (0.f + tn.w);
+        op.x = 0.f + (-tp.x); op.y = 0.f + (-tp.y); op.z = 0.f + (-tp.z); op.w = 0.f + (-tp.w);
+        on.x = 0.f + (-tn.x); on.y = 0.f + (-tn.y); on.z = 0.f + (-tn.z); on.w = 0.f + (-tn.w);
+        stream_store(dq4 + b4 + i, oq);
+        stream_store(dp4 + b4 + i, op);
+        stream_store(dn4 + b4 + i, on);
+      }
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const bool have = r0 + t < N;
+    const long long row = have ? r0 + t : (long long)N - 1;
+    const float4* im = lds4 + ((size_t)wave * 4 + 2 * t + br) * ST4;
+    SpecSegment<H4> sg;
+    sg.load(im + spec_seg32(j) * H4);
+    // window centres: tree sums of segment 0 / segments 0-1, read back from the image (as euclid_block_kernel)
+    const bool last_ok = (LASTN >= 32) || (j < LASTN);
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < PNIT; ++it) {
+      const bool valid = (it < PNIT - 1) || last_ok;
+      const float4 sq = im[valid ? j + 32 * it : 0];
+      const float s4 = valid ? (sq.x + sq.y) + (sq.z + sq.w) : 0.f;
+      const int i = j + 32 * it;
+      if (32 * it + 31 < H4) p1 += s4;
+      else if (32 * it < H4) p1 += (i < H4) ? s4 : 0.f;
+      if (32 * it + 31 < 2 * H4) p2 += s4;
+      else if (32 * it < 2 * H4) p2 += (i < 2 * H4) ? s4 : 0.f;
+    }
+    p1 = half_wave_sum(p1);
+    p2 = half_wave_sum(p2);
+    __builtin_amdgcn_s_setprio(3);
+    const float2v start = spec_start32(p1, p2, j);
+    const float2v end = sg.chain(start);
+    bool hit;
+    float dist = spec_resolve_halves(start, end, j, &hit);
+    if (!hit) {
+      MMS_COUNT_MISS();
+      dist = chain_sum_lds(im, ST4, 0.0f);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    const float Tmine = 1.0f / (1.0f + sqrtf(dist));
+    const float Tp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tmine), 0));
+    const float Tn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tmine), 32));
+    const PairTerm pt = pair_term(Tp, Tn, yy[t], margin);
+    float ga, gb;
+    pair_grad(yy[t], pt.ordered, pt.similar, s0, s1, ga, gb, hinge_ge != 0);
+    if (EXACT) { k0[t] = euclid_coef(Tp, ga); k1[t] = euclid_coef(Tn, gb); }
+    else {
+      c0[t] = ga * Tp * Tp * Tp; c1[t] = gb * Tn * Tn * Tn;
+      rr0[t] = (float)rcp_newton((double)(Tp - 1.0f) + 1e-9);
+      rr1[t] = (float)rcp_newton((double)(Tn - 1.0f) + 1e-9);
+    }
+    if (INL) {
+      const float tm = have ? pt.term : 0.f;
+      const bool ok = tm >= 0.f && tm < (float)(1 << kFxTermBits);
+      fx_sum += ok ? (unsigned long long)((double)tm * fx_scale) : 0ull;
+      fx_bad += ok ? 0ull : 1ull;
+      if (t == 1 && lane == 0) {                   // the wave's two terms arrive together (see triplet32_kernel)
+        const unsigned long long pay = (1ull << 60) | (fx_bad ? kFxOne : 0ull) | fx_sum;
+        const unsigned long long old = __hip_atomic_fetch_add(&wg_arrivals, pay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((old >> 60) == (unsigned long long)(WPB - 1)) {
+          const unsigned long long wg = old + pay;
+          const unsigned grp = blockIdx.x / kTicketGroup;
+          const unsigned gsize = min((unsigned)kTicketGroup, gridDim.x - (unsigned)kTicketGroup * grp);
+          const unsigned long long gpay = kFxOne | (wg & kFxSumMask);
+          if ((wg >> kFxSumBits) & 0xffull)
+            __hip_atomic_fetch_or(ticket + grp, kFxPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long gold = __hip_atomic_fetch_add(ticket + grp, gpay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (((gold >> kFxSumBits) & 0x7ffull) == (unsigned long long)(gsize - 1)) {
+            const unsigned long long g = gold + gpay;
+            __hip_atomic_store(ticket + grp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            top_pay = kFxOne | (g & kFxSumMask);
+            if (g & kFxPoison) __hip_atomic_fetch_or(ticket + kTicketTop, kFxPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            top_old = __hip_atomic_fetch_add(ticket + kTicketTop, top_pay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            top_wait = true;
+          }
+        }
+      }
+    } else {
+      if (lane == 0 && have) partials[row] = pt.term;
+    }
+    if (lane == 0 && have) { s_pos[row] = Tp; s_neg[row] = Tn; }
+    if (!LATE) store_pass(t);
+  }
+  if (LATE) { store_pass(0); store_pass(1); }
+  if (!INL) return;
+  if (top_wait) {
+    const unsigned ngrp = (gridDim.x + kTicketGroup - 1) / kTicketGroup;
+    if (((top_old >> kFxSumBits) & 0x7ffull) == (unsigned long long)(ngrp - 1)) {
+      const unsigned long long all = top_old + top_pay;
+      __hip_atomic_store(ticket + kTicketTop, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float sum = (float)((double)(all & kFxSumMask) / fx_scale);
+      *loss = (all & kFxPoison) ? __builtin_nanf("") : sum / (float)N;                       // pair_rank_loss_layer.cpp:49
+    }
+  }
+}
+
 // Generic fallback (any D / alignment): a workgroup owns ROWS triplets.
 template <int ROWS, int THREADS>
 __global__ __launch_bounds__(THREADS) void triplet_generic_kernel(
@@ -619,11 +824,21 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
   if (v && (D == 300 || D == 200 || D == 100)) {
     constexpr int WPB = 8;
     nparts = N;
-    const unsigned grid = (unsigned)((N + WPB - 1) / WPB);
+    // dev switch for A/B timing (tools/triplet_probe.py): MMS_TRIPLET_TPW = 1 | 2 triplets per wave
+    static const int tpw = [] { const char* e = std::getenv("MMS_TRIPLET_TPW"); return e && std::atoi(e) == 1 ? 1 : 2; }();
+    const unsigned grid = (unsigned)((N + WPB * tpw - 1) / (WPB * tpw));
     const bool exact = euclid_backward_mode() == MMS_EUCLID_BWD_REFERENCE;
 #define MMS_T32_GO(d4, ex, inl)                                                                        \
-  hipLaunchKernelGGL((triplet32_kernel<d4, ex, WPB, inl>), dim3(grid), dim3(64 * WPB), 0, s, N, margin,  \
-                     s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan, hge, tk, loss, fx_scale)
+  do {                                                                                                     \
+    if (tpw == 2)                                                                                          \
+      hipLaunchKernelGGL((triplet32x2_kernel<d4, ex, WPB, inl>), dim3(grid), dim3(64 * WPB), 0, s, N,      \
+                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan, hge, tk,      \
+                         loss, fx_scale);                                                                  \
+    else                                                                                                   \
+      hipLaunchKernelGGL((triplet32_kernel<d4, ex, WPB, inl>), dim3(grid), dim3(64 * WPB), 0, s, N,        \
+                         margin, s0, s1, q, ap, an, y, s_pos, s_neg, partials, dq, dap, dan, hge, tk,      \
+                         loss, fx_scale);                                                                  \
+  } while (0)
 #define MMS_T32(d4)                                                       \
   case 4 * d4:                                                            \
     if (exact) { if (tk) MMS_T32_GO(d4, true, true); else MMS_T32_GO(d4, true, false); }     \
