@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void triplet_wave_kernel(
     const int ii = i < D4 ? i : 0;
     x[it] = q4[ii]; u[it] = p4[ii]; v[it] = m4[ii];
   }
-  const float yy = y[row];
+  float yy = y[row];
   float predp1 = 0.f, predp2 = 0.f, predn1 = 0.f, predn2 = 0.f;
   const int h4 = spec_h4(D4);
 #pragma unroll
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(256) void triplet_wave_kernel(
   }
   const float Tmine = 1.0f / (1.0f + sqrtf(dist));
   const float Tp = __shfl(Tmine, 0, 64), Tn = __shfl(Tmine, 32, 64);
+  asm volatile("" : "+v"(yy));   // in a register before the stores below (see triplet32_kernel)
   if (lane == 0) { s_pos[row] = Tp; s_neg[row] = Tn; }
 
   // PairRankLoss on (Tp, Tn, y): every lane computes the same scalars
