@@ -58,6 +58,9 @@ const char* mms_error_string(int code);
  *       1e-5).  Used by the kernels specialised for D = 100 / 200 / 300 in the
  *       one-word geometry (SimCross and the fused triplet step) and by the tiled
  *       word-grid backward; every other kernel always runs the reference mode.
+ *       For batches of >= 512 narrow word grids (D <= 64) the word-grid backward also
+ *       sums da over the rows j in two halves (two waves per pair) and adds the halves:
+ *       one association away from the reference's j-ascending sum, within the same bar.
  *   MMS_EUCLID_BWD_REFERENCE: the reference's bits, everywhere.
  * The mode belongs to the CALLING THREAD (a Caffe host drives each GPU from its own thread, and so does its
  * `Caffe` singleton, src/caffe/common.cpp:13-15): mms_set_euclid_backward_mode changes it for the calling

@@ -1588,14 +1588,22 @@ static size_t cross_bwd_tiled_lds(int mode, int W1, int W2) {
 // W2 is a compile-time constant (even; the widths the dispatcher instantiates -- the reference pads sentences to
 // one length, 40 in network_v4): the k loop is straight-line code, two k per packed sub / mul / mul, with all
 // of a row's coefficient reads in flight together.  Other widths keep cross_bwd_tiled_kernel.
-template <int W2C, bool EXACT>
-__global__ __launch_bounds__(64) void cross_bwd_lane_kernel(
+// NW = 2 (fp32 arithmetic only): TWO waves per pair, wave w takes the rows j of half w -- its own rows of the
+// coefficient table, its own rows of dq (complete, k ascending as before), and a partial da over its rows; da is
+// the sum of the two partials (one association away from the j-ascending sum: inside the mode's 2-ulp-per-term
+// contract, not bit-identical -- the reference-rounding mode keeps one wave per pair).  1517 pairs are 1.5 waves
+// per SIMD with one wave per pair -- the launch takes as long as the SIMDs that hold two -- and 3 with two.
+template <int W2C, bool EXACT, int NW = 1>
+__global__ __launch_bounds__(64 * NW) void cross_bwd_lane_kernel(
     const float* __restrict__ q, const float* __restrict__ a, const float* __restrict__ top,
     const float* __restrict__ top_diff, float* __restrict__ dq, float* __restrict__ da, int W1, int D) {
   static_assert(W2C % 2 == 0, "two k per packed operation");
+  static_assert(NW == 1 || !EXACT, "the reference-rounding mode sums da in j order: one wave per pair");
   constexpr int KP = W2C / 2;
   extern __shared__ __attribute__((aligned(16))) double lds_lane[];
-  const int n = blockIdx.x, lane = threadIdx.x;
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int JH = (W1 + NW - 1) / NW;                       // rows per wave
+  const int jb = min(wv * JH, W1), je = min(jb + JH, W1);
   const int JK = W1 * W2C;
   // tables (index e = j*W2C + k, the blob's own order): EXACT: double den[], double rcp[], float c[];
   // otherwise float2 (c, fl32(1/den))[]
@@ -1605,14 +1613,15 @@ __global__ __launch_bounds__(64) void cross_bwd_lane_kernel(
   // fp32 mode: W2C/2 float4 (c_k, c_k+1, r_k, r_k+1) per row j
   const float* Tn = top + (size_t)n * JK;
   const float* gn = top_diff + (size_t)n * JK;
-  for (int e0 = lane; e0 < JK; e0 += 64 * 8) {
+  const int eb = jb * W2C, ee = je * W2C;                  // this wave's rows of the table
+  for (int e0 = eb + lane; e0 < ee; e0 += 64 * 8) {
     float tv[8], gv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) { const int e = min(e0 + 64 * u, JK - 1); tv[u] = Tn[e]; gv[u] = gn[e]; }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + 64 * u;
-      if (e >= JK) break;
+      if (e >= ee) break;
       const EuclidCoef kc = euclid_coef(tv[u], gv[u]);
       if (EXACT) { t_c[e] = kc.c; t_den[e] = kc.den; t_rcp[e] = kc.rcp; }
       else {                                             // per k pair: (c_k, c_k+1, r_k, r_k+1)
@@ -1670,8 +1679,8 @@ __global__ __launch_bounds__(64) void cross_bwd_lane_kernel(
     // wave-uniform addresses: five s_load_dwordx16 per row, SGPR operands of the packed multiplies) was built and
     // measured: 61 us -- 80 SGPRs per row leave no room to run the loads ahead, so each row exposes its
     // scalar-cache misses (the 19 MB table streams through once).
-    float qv = qn[0];
-    for (int j = 0; j < W1; ++j) {
+    float qv = qn[(size_t)min(jb, W1 - 1) * D];
+    for (int j = jb; j < je; ++j) {
       const float qnext = qn[(size_t)min(j + 1, W1 - 1) * D];
       const float2v qq = {qv, qv};
       float4v cr[KP];
@@ -1691,6 +1700,17 @@ __global__ __launch_bounds__(64) void cross_bwd_lane_kernel(
     }
   }
   float* dan = da + (size_t)n * W2C * D + d;
+  if (NW == 2) {                                             // wave 1 hands its partial da to wave 0 through LDS
+    float2v* part = reinterpret_cast<float2v*>(reinterpret_cast<float*>(lds_lane) + 2 * JK);   // behind the table
+    if (wv == 1) {
+#pragma unroll
+      for (int kp = 0; kp < KP; ++kp) part[kp * 64 + lane] = acc[kp];
+    }
+    __syncthreads();
+    if (wv == 1) return;
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) acc[kp] = acc[kp] + part[kp * 64 + lane];
+  }
   if (live) {
 #pragma unroll
     for (int kp = 0; kp < KP; ++kp) {
@@ -1700,7 +1720,8 @@ __global__ __launch_bounds__(64) void cross_bwd_lane_kernel(
   }
 }
 static size_t cross_bwd_lane_lds(bool exact, int W1, int W2) {
-  return (size_t)W1 * W2 * (exact ? 8 + 8 + 4 : 8) + 16;
+  // fp32 mode: the table, then the second wave's partial da (W2 floats per lane)
+  return (size_t)W1 * W2 * (exact ? 8 + 8 + 4 : 8) + (exact ? 0 : (size_t)W2 * 64 * sizeof(float)) + 16;
 }
 // the lane kernel pays when there are enough pairs to give every SIMD a wave and the grids are narrow
 static bool cross_bwd_lane_ok(bool exact, int N, int W1, int W2, int D) {
@@ -1990,8 +2011,8 @@ int simcross_elementwise_backward(int mode, int N, int W1, int W2, int D,
       hipLaunchKernelGGL((cross_bwd_lane_kernel<W2_, true>), dim3((unsigned)N), dim3(64), lds, s, q, a,   \
                          top, top_diff, dq, da, W1, D);                                                   \
     else                                                                                                  \
-      hipLaunchKernelGGL((cross_bwd_lane_kernel<W2_, false>), dim3((unsigned)N), dim3(64), lds, s, q, a,  \
-                         top, top_diff, dq, da, W1, D);                                                   \
+      hipLaunchKernelGGL((cross_bwd_lane_kernel<W2_, false, 2>), dim3((unsigned)N), dim3(128), lds, s, q, \
+                         a, top, top_diff, dq, da, W1, D);                                                \
     break;
     switch (W2) { MMS_LANE(8) MMS_LANE(16) MMS_LANE(20) MMS_LANE(24) MMS_LANE(32) MMS_LANE(40) MMS_LANE(48) }
 #undef MMS_LANE

@@ -116,7 +116,8 @@ def test_triplet_step_fp32_mode(N, D, oracle, hiplib):
 
 
 @pytest.mark.parametrize("shape", [(50, 40, 40, 50), (7, 40, 40, 300), (3, 5, 9, 33),
-                                   (600, 40, 40, 50), (513, 7, 8, 33), (520, 47, 48, 64), (515, 9, 20, 50)])   # lane-per-column kernel
+                                   (600, 40, 40, 50), (513, 7, 8, 33), (520, 47, 48, 64), (515, 9, 20, 50),
+                                   (530, 33, 40, 50), (600, 1, 8, 16)])   # lane-per-column kernel (two waves per pair in fp32 mode: odd W1, W1 = 1)
 def test_cross_geometry_fp32_mode(shape, oracle, hiplib):
     """Word-grid geometry (W1 x W2 scores per pair): scores exact; each gradient element is a sum of
     W terms that are each within 2 ulp, so it is held to the north-star bar against the largest
