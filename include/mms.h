@@ -97,6 +97,21 @@ int mms_dot_f64(int n, const double* x, const double* y, double* out, void* stre
 int mms_set_pairrank_hinge_mode(int mode);
 int mms_get_pairrank_hinge_mode(void);
 
+/* How PairRankLoss's loss scalar is summed (mms_pairrank_forward_f32 and the fused triplet step; per calling
+ * thread, like the modes above).
+ *   MMS_LOSS_SUM_FAST (default): an order-free sum of the bit-exact per-element terms (fixed-shape tree, or integer
+ *       arithmetic inside the fused step): within 2e-6 of the exact mean, hence within 1e-5 of the reference's value
+ *       wherever that value is itself within 1e-5 of the exact mean.
+ *   MMS_LOSS_SUM_REFERENCE: Forward_cpu's own sum, ONE running fp32 accumulator over the terms in index order
+ *       (pair_rank_loss_layer.cpp:41-49): the CPU code's bits, including its drift for thousands of near-constant
+ *       terms (every add of ~2 to a partial sum in [4096, 8192) rounds the same way: 1-2e-5 relative at N = 4096).
+ *       A dependent chain of `count` adds by one lane, ~3 ns each, in one extra one-workgroup launch; the fused
+ *       step then sums by a second launch whatever its finish mode. */
+#define MMS_LOSS_SUM_FAST 0
+#define MMS_LOSS_SUM_REFERENCE 1
+int mms_set_loss_sum_mode(int mode);
+int mms_get_loss_sum_mode(void);
+
 /* ------------------------------------------------------------------------- *
  * SimCross  (q (N,W1,D), a (N,W2,D) -> top (N, M|1, W1, W2))
  * ------------------------------------------------------------------------- */
@@ -269,7 +284,7 @@ size_t mms_pairrank_workspace_bytes(int count);
  * Outputs equal the layer-by-layer result bitwise, except the loss scalar: it is within 2e-6 of the exact mean of
  * the (bit-exact) per-triplet terms, hence within 1e-5 of the reference's value wherever the reference's fp32
  * running sum is itself that close to the exact mean (for thousands of near-constant terms it drifts by 1-2e-5:
- * DESIGN.md 5).
+ * DESIGN.md 5); bit-identical to the reference's in MMS_LOSS_SUM_REFERENCE mode (above).
  * loss_partials: mms_triplet_workspace_bytes(N) bytes of device scratch.
  * ------------------------------------------------------------------------- */
 /* How the loss scalar of the fused step is summed (per calling thread):

@@ -58,6 +58,8 @@ _SIGNATURES = {
     "mms_dot_f64": (_i, [_i, _vp, _vp, _vp, _vp]),
     "mms_set_f16_distance_mode": (_i, [_i]),
     "mms_get_f16_distance_mode": (_i, []),
+    "mms_set_loss_sum_mode": (_i, [_i]),
+    "mms_get_loss_sum_mode": (_i, []),
     "mms_set_triplet_finish_mode": (_i, [_i]),
     "mms_get_triplet_finish_mode": (_i, []),
     "mms_set_pairrank_hinge_mode": (_i, [_i]),
@@ -401,6 +403,13 @@ def set_f16_distance_mode(mode):
     ~1e-6 relative, no ordered chain.  Per calling thread; fp16-storage entry points only."""
     m = {"ordered": 0, "tree": 1}[mode] if isinstance(mode, str) else int(mode)
     check(lib().mms_set_f16_distance_mode(m), "mms_set_f16_distance_mode")
+
+
+def set_loss_sum_mode(mode):
+    """'fast' (default): order-free sum of the loss terms; 'reference': Forward_cpu's running fp32 sum, bit for bit
+    (include/mms.h: MMS_LOSS_SUM_*)."""
+    m = {"fast": 0, "reference": 1}[mode] if isinstance(mode, str) else int(mode)
+    check(lib().mms_set_loss_sum_mode(m), "mms_set_loss_sum_mode")
 
 
 def set_triplet_finish_mode(mode):

@@ -70,6 +70,8 @@ int pairrank_hinge_mode();
 void set_pairrank_hinge_mode(int m);
 int triplet_finish_mode();
 void set_triplet_finish_mode(int m);
+int loss_sum_mode();
+void set_loss_sum_mode(int m);
 int f16_distance_mode();
 void set_f16_distance_mode(int m);
 // f64_paths.hip
@@ -459,6 +461,13 @@ int mms_set_triplet_finish_mode(int mode) {
   return MMS_OK;
 }
 int mms_get_triplet_finish_mode(void) { return triplet_finish_mode(); }
+
+int mms_set_loss_sum_mode(int mode) {
+  if (mode != MMS_LOSS_SUM_FAST && mode != MMS_LOSS_SUM_REFERENCE) return MMS_ERR_INVALID_ARG;
+  set_loss_sum_mode(mode);
+  return MMS_OK;
+}
+int mms_get_loss_sum_mode(void) { return loss_sum_mode(); }
 int mms_set_f16_distance_mode(int mode) {
   if (mode != MMS_F16_DISTANCE_ORDERED && mode != MMS_F16_DISTANCE_TREE) return MMS_ERR_INVALID_ARG;
   set_f16_distance_mode(mode);

@@ -42,6 +42,9 @@ constexpr unsigned long long kFxSumMask = kFxOne - 1;
 static thread_local int t_hinge_mode = MMS_PAIRRANK_HINGE_CPU;
 int pairrank_hinge_mode() { return t_hinge_mode; }
 void set_pairrank_hinge_mode(int m) { t_hinge_mode = m; }
+static thread_local int t_loss_sum = MMS_LOSS_SUM_FAST;
+int loss_sum_mode() { return t_loss_sum; }
+void set_loss_sum_mode(int m) { t_loss_sum = m; }
 static thread_local int t_triplet_finish = MMS_TRIPLET_FINISH_INLAUNCH;
 int triplet_finish_mode() { return t_triplet_finish; }
 void set_triplet_finish_mode(int m) { t_triplet_finish = m; }
@@ -119,6 +122,54 @@ __global__ __launch_bounds__(kPairThreads) void loss_finish_kernel(
   if (threadIdx.x == 0) *loss = s / (float)count;
 }
 
+// MMS_LOSS_SUM_REFERENCE: the reference's own sum -- ONE running fp32 accumulator over the terms in index order
+// (pair_rank_loss_layer.cpp:41-49) -- so that the loss scalar carries the CPU code's bits, drift and all.  A
+// dependent chain of `count` adds by one lane (~3 ns each); the other threads only stage the next terms in LDS.
+// terms != nullptr: the per-element terms as the fused step stored them; otherwise they are formed from the
+// layer's own outputs, max(0, ordered) + |(1 - y) * similar| (:43-44).
+constexpr int kRunChunk = 4096;
+__global__ __launch_bounds__(256) void loss_running_sum_kernel(
+    const float* __restrict__ terms, const float* __restrict__ ordered, const float* __restrict__ similar,
+    const float* __restrict__ y, int count, float* __restrict__ loss) {
+  __shared__ float buf[2][kRunChunk];
+  auto stage = [&](int b, int base, int first, int nthreads) {   // threads [first, first + nthreads) fill buf[b]
+    for (int e = (int)threadIdx.x - first; e < kRunChunk; e += nthreads) {
+      const int i = base + e;
+      float t = 0.f;
+      if (i < count) {
+        if (terms) t = terms[i];
+        else {
+          const float o = ordered[i];
+          const float hinge = (0.0f < o) ? o : 0.0f;
+          t = hinge + fabsf((1.0f - y[i]) * similar[i]);
+        }
+      }
+      buf[b][e] = t;
+    }
+  };
+  stage(0, 0, 0, 256);
+  __syncthreads();
+  float l = 0.f;
+  for (int base = 0, b = 0; base < count; base += kRunChunk, b ^= 1) {
+    if (threadIdx.x >= 64) {                       // the other waves fetch the next chunk meanwhile
+      if (base + kRunChunk < count) stage(b ^ 1, base + kRunChunk, 64, 192);
+    } else if (threadIdx.x == 0) {
+      const int n = min(kRunChunk, count - base);
+      int e = 0;
+      for (; e + 8 <= n; e += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = buf[b][e + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) l += v[u];
+      }
+      for (; e < n; ++e) l += buf[b][e];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = l / (float)count;  // :49
+}
+
 __global__ __launch_bounds__(256) void pairrank_bwd_kernel(
     int count, float s0, float s1, const float* __restrict__ y,
     const float* __restrict__ ordered, const float* __restrict__ similar,
@@ -184,6 +235,9 @@ int pairrank_forward(int count, float margin, const float* a, const float* b, co
   if (count <= kSmallMax) {
     hipLaunchKernelGGL(pairrank_fwd_small_kernel, dim3(1), dim3(kSmallThreads), 0, s, count, margin, a,
                        b, y, ordered, similar, loss);
+    if (loss_sum_mode() == MMS_LOSS_SUM_REFERENCE)
+      hipLaunchKernelGGL(loss_running_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)nullptr, ordered,
+                         similar, y, count, loss);
     return launch_status();
   }
   const int blocks = pair_blocks(count);
@@ -192,7 +246,10 @@ int pairrank_forward(int count, float margin, const float* a, const float* b, co
   float* partials = static_cast<float*>(ws);
   hipLaunchKernelGGL(pairrank_fwd_kernel, dim3(blocks), dim3(kPairThreads), 0, s, count, margin,
                      a, b, y, ordered, similar, partials, loss);
-  if (blocks > 1)
+  if (loss_sum_mode() == MMS_LOSS_SUM_REFERENCE)
+    hipLaunchKernelGGL(loss_running_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)nullptr, ordered,
+                       similar, y, count, loss);
+  else if (blocks > 1)
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kPairThreads), 0, s, partials, blocks,
                        count, loss);
   return launch_status();
@@ -766,13 +823,7 @@ __global__ __launch_bounds__(THREADS) void triplet_generic_kernel(
     terms[r] = t;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    // same association as the wave kernel's (pair partials, then the finish tree)
-    // is not required: the loss is held to 1e-5, not bitwise.
-    float s = 0.f;
-    for (int r = 0; r < ROWS; ++r) s += terms[r];
-    partials[blockIdx.x] = s;
-  }
+  if (threadIdx.x < rows) partials[row0 + threadIdx.x] = terms[threadIdx.x];   // one term per triplet, like the wave kernels
   for (int i = threadIdx.x; i < total; i += THREADS) {
     const int r = i / D;
     const float tp = euclid_tt_exact(cs[0][r], dens[0][r], dpos[i]);
@@ -806,7 +857,7 @@ static unsigned long long* next_ticket_slot() {
   return base + (size_t)(next.fetch_add(1, std::memory_order_relaxed) % kTicketSlots) * kTicketStride;
 }
 
-// one float per triplet (wave kernel) -- the generic kernel needs fewer
+// one float per triplet
 size_t triplet_workspace_bytes(int N) { return (size_t)N * sizeof(float); }
 
 int triplet_euclid_step(int N, int D, float margin, float loss_weight, const float* q,
@@ -849,7 +900,8 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
     // the sum: see the kernel); otherwise, and for batches beyond what a ticket slot covers, the per-triplet
     // terms are summed by a second, one-workgroup launch.
     const unsigned ngrp = (grid + kTicketGroup - 1) / kTicketGroup;
-    unsigned long long* tk = (triplet_finish_mode() != MMS_TRIPLET_FINISH_INLAUNCH || ngrp > (unsigned)kTicketTop)
+    unsigned long long* tk = (triplet_finish_mode() != MMS_TRIPLET_FINISH_INLAUNCH || ngrp > (unsigned)kTicketTop ||
+                              loss_sum_mode() == MMS_LOSS_SUM_REFERENCE)
                                  ? nullptr : next_ticket_slot();
     int lg = 0;
     while (((long long)1 << lg) < (long long)N) ++lg;
@@ -879,13 +931,17 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
   } else {
     const size_t lds = 2 * (size_t)kTripRows * D * sizeof(float);
     if (lds > 96 * 1024) return MMS_ERR_UNSUPPORTED;
-    nparts = (N + kTripRows - 1) / kTripRows;
+    nparts = N;
     hipLaunchKernelGGL((triplet_generic_kernel<kTripRows, kTripThreads>), dim3(nparts),
                        dim3(kTripThreads), lds, s, N, D, margin, s0, s1, q, ap, an, y, s_pos,
                        s_neg, partials, dq, dap, dan, hge);
   }
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kPairThreads), 0, s, partials, nparts, N,
-                     loss);
+  if (loss_sum_mode() == MMS_LOSS_SUM_REFERENCE)   // nparts == N on every path: one term per triplet
+    hipLaunchKernelGGL(loss_running_sum_kernel, dim3(1), dim3(256), 0, s, partials, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, N, loss);
+  else
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kPairThreads), 0, s, partials, nparts, N,
+                       loss);
   return launch_status();
 }
 

@@ -539,6 +539,47 @@ def test_pairrank(cfg, oracle, hiplib):
     assert_bitexact(host(gb2), db_ref)
 
 
+@pytest.mark.parametrize("N", [1, 77, 4095, 8192, 8193, 20001])
+def test_loss_sum_reference_mode_is_bit_identical(N, oracle, hiplib):
+    """MMS_LOSS_SUM_REFERENCE reproduces Forward_cpu's running fp32 sum (pair_rank_loss_layer.cpp:41-49) bit for bit,
+    on data where that sum drifts from the exact mean by more than 1e-5 (near-constant terms of about 2): the default
+    order-free sum stays within 2e-6 of the exact mean instead.  PairRankLoss alone and the fused triplet step."""
+    from mms_answer_selection_amd import capi
+    r = rng(N)
+    a = (0.5 + 1e-3 * r.standard_normal((N, 1))).astype(np.float32)
+    b = (0.5 + 1e-3 * r.standard_normal((N, 1))).astype(np.float32)
+    y = (r.uniform(size=(N, 1)) < 0.8).astype(np.float32)
+    margin = 2.0
+    loss_ref, ord_ref, sim_ref = oracle.pairrank_forward(a, b, y, margin)
+    exact = float((np.maximum(0.0, ord_ref.astype(np.float64)) + np.abs((1.0 - y.astype(np.float64)) * sim_ref.astype(np.float64))).mean())
+    o, s_, loss = nan_like(a.shape), nan_like(a.shape), nan_like((1,))
+    capi.pairrank_forward(dev(a), dev(b), dev(y), o, s_, loss, margin=margin)
+    assert abs(host(loss)[0] - exact) <= 2e-6 * max(1.0, abs(exact))
+    capi.set_loss_sum_mode("reference")
+    try:
+        loss2 = nan_like((1,))
+        capi.pairrank_forward(dev(a), dev(b), dev(y), o, s_, loss2, margin=margin)
+        assert_bitexact(host(loss2), np.array([loss_ref], np.float32), "PairRankLoss loss, reference sum")
+        assert_bitexact(host(o), ord_ref)
+        # the fused step: widths of the specialised kernels and of the generic ones
+        for D in ((300, 52) if N <= 8193 else (100,)):
+            q = (r.standard_normal((N, 1, D)) * 1e-3).astype(np.float32)
+            ap = (q + r.standard_normal((N, 1, D)) * 1e-5).astype(np.float32)
+            an = (q + r.standard_normal((N, 1, D)) * 1e-4).astype(np.float32)
+            sp, _, _ = oracle.simcross_forward(1, q, ap)
+            sn, _, _ = oracle.simcross_forward(1, q, an)
+            lref, _, _ = oracle.pairrank_forward(sp.reshape(N, 1), sn.reshape(N, 1), y, margin)
+            out = dict(s_pos=nan_like((N, 1)), s_neg=nan_like((N, 1)), loss=nan_like((1,)),
+                       dq=nan_like(q.shape), da_pos=nan_like(q.shape), da_neg=nan_like(q.shape))
+            capi.triplet_euclid_step(dev(q), dev(ap), dev(an), dev(y), margin=margin, **out)
+            assert_bitexact(host(out["loss"]), np.array([lref], np.float32), "triplet loss, reference sum, D=%d" % D)
+            assert_bitexact(host(out["s_pos"]).ravel(), sp.ravel())
+    finally:
+        capi.set_loss_sum_mode("fast")
+    assert hiplib.mms_set_loss_sum_mode(5) == 1                   # MMS_ERR_INVALID_ARG
+    assert hiplib.mms_get_loss_sum_mode() == 0
+
+
 def test_pairrank_hinge_comparison_modes(oracle, hiplib):
     """Where margin - y*(a-b) is EXACTLY zero the reference's two backward implementations disagree:
     Backward_cpu gates the hinge term with `ordered > 0` (pair_rank_loss_layer.cpp:76, the default here and the

@@ -50,5 +50,14 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
             bad += 1
             print("MISMATCH seed", seed, "mode", mode, "N", N, "D", D, "kind", kind, "loss", h["loss"][0], loss_ref)
         total += N
+    # MMS_LOSS_SUM_REFERENCE: the oracle's running fp32 sum, bit for bit
+    capi.set_loss_sum_mode("reference")
+    lo = torch.full((1,), float("nan"), device="cuda")
+    out["loss"] = lo
+    capi.triplet_euclid_step(dev(q), dev(ap), dev(an), dev(y), margin=margin, **out)
+    capi.set_loss_sum_mode("fast")
+    if lo.cpu().numpy().view(np.uint32)[0] != np.float32(loss_ref).view(np.uint32):
+        bad += 1
+        print("MISMATCH (reference loss sum) seed", seed, "N", N, "D", D, lo.item(), loss_ref)
 capi.set_triplet_finish_mode("inlaunch")
 print("triplets checked (both modes): %d, mismatching batches: %d, batches where the oracle's float32 running sum is itself > 1e-5 from the exact mean: %d, %.1f s" % (total, bad, drifted, time.time() - t0))
