@@ -1050,6 +1050,16 @@ def other_configs(torch, capi):
         b = 4.0 * (2 * n * 40 * 50 + n * 1600)                       # SURVEY 8(d) B_fwd
         out[name] = {"us_per_step": us, "pairs_per_s": n / (us * 1e-6), "GBps_algorithmic": b / us / 1e3,
                      "bound": "fp32 VALU (3 flop per (j,k,d), d-ordered sums)"}
+        if n == 1517:       # ... and the BACKWARD of the same geometry (training on word grids; default fp32 backward arithmetic)
+            dtg = torch.randn(n, 1, 40, 40, device="cuda", generator=g)
+            dqg, dag = torch.empty_like(qg), torch.empty_like(ag)
+            capi.simcross_forward(1, qg, ag, tg)
+            usb = _graph_time(torch, lambda: capi.simcross_backward(1, qg, ag, tg, dtg, dqg, dag))
+            out["cfg4_euclid_backward_1517x40x40x50"] = {
+                "us_per_step": usb, "pairs_per_s": n / (usb * 1e-6),
+                "note": "cross_bwd_lane_kernel, two waves per pair; every (j,k,d) term formed once",
+                "bound": "LDS return path + fp32 VALU issue"}
+            del dtg, dqg, dag
         del qg, ag, tg
     # cfg 4 in the mode the reference's network_v4 scores with: SimCross bilinear, M = 4, bias (forward only)
     n = 1517
