@@ -318,7 +318,10 @@ size_t mms_triplet_workspace_bytes(int N);
  * define "ranking output": with the Euclidean scores bit-identical to the CPU
  * code, MAP/MRR/AUC computed here are bit-identical too wherever the sort order
  * is defined (ties between EQUAL scores are implementation-defined in the
- * reference's unstable std::sort; here they keep original order).
+ * reference's unstable std::sort; here they keep original order -- which is also what
+ * libstdc++'s std::sort does for a bucket of at most 16 items, its stable insertion sort:
+ * MAP / MRR over candidate groups that small match a libstdc++ build of the reference bit
+ * for bit even when tied scores carry different labels).
  * ------------------------------------------------------------------------- */
 
 /* Replaces MAPLayer<float>::Forward_cpu (src/caffe/layers/map_layer.cpp:41-100) and

@@ -17,7 +17,9 @@
 // to the CPU code whenever the order is defined.  Ties: std::sort is unstable,
 // so the reference's order among EQUAL scores is implementation-defined; the
 // radix sort is stable (original index ascending).  Results can differ from a
-// particular libstdc++ only when equal scores carry different labels.
+// particular libstdc++ only when equal scores carry different labels IN A BUCKET OF MORE THAN 16 ITEMS: up to
+// 16, std::sort is libstdc++'s insertion sort, which is stable -- the same order as here
+// (tests/test_gpu_ranking.py, tools/soak_ranking_embed.py).
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>

@@ -112,6 +112,29 @@ def test_skipped_buckets_and_empty_result(oracle, hiplib):
     assert capi.rank_auc(dev(prob), dev(np.zeros(5, np.float32))) == 0.0
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_cross_label_ties_in_groups_of_at_most_16_follow_the_reference(seed, oracle, hiplib):
+    """std::sort on at most 16 elements is libstdc++'s insertion sort, which is stable: for candidate groups that
+    small the reference's order among EQUAL scores is the input order -- the library's own tie rule -- so MAP and
+    MRR carry the reference's bits even when tied scores have different labels (map_layer.cpp:76, mrr_layer.cpp:57)."""
+    from mms_answer_selection_amd import capi
+    r = rng(400 + seed)
+    ng = [1, 7, 60, 300, 900, 40][seed]
+    sizes = r.integers(1, 17, ng)
+    gid = np.repeat(np.arange(ng), sizes).astype(np.float32) - 2
+    n = gid.size
+    gid = gid[r.permutation(n)]
+    label = (r.uniform(size=n) < 0.4).astype(np.float32)
+    score = (np.round(r.uniform(0, 1, n) * 4) / 4).astype(np.float32)        # five score levels: ties everywhere
+    prob = np.stack([1 - score, score], 1).astype(np.float32)
+    m_ref, eff_ref = oracle.map_score(prob, label, gid)
+    rr_ref, _ = oracle.mrr_score(prob, label, gid)
+    m, rr, eff = capi.rank_map_mrr(dev(prob), dev(label), dev(gid))
+    assert eff == eff_ref
+    assert same_bits(m, m_ref) or (np.isnan(m) and np.isnan(m_ref)), (m, m_ref)
+    assert same_bits(rr, rr_ref) or (np.isnan(rr) and np.isnan(rr_ref)), (rr, rr_ref)
+
+
 def test_ties_with_equal_labels_are_order_independent(oracle, hiplib):
     """Equal scores: the reference's order is implementation-defined (unstable sort);
     when the tied items share a label every order gives the same metric."""

@@ -40,6 +40,21 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     if q: a = (np.round(a * q) / q).astype(np.float32); b = (np.round(b * q) / q).astype(np.float32)
     ra, ra_ref = capi.rank_accuracy(dev(a), dev(b), dev(label)), O.rank_accuracy(a, b, label)
     chk(bits(ra) == bits(ra_ref), tag + " rank_accuracy %r vs %r" % (ra, ra_ref))
+    # TIED scores across labels, candidate groups of at most 16: libstdc++'s std::sort is then its (stable)
+    # insertion sort, so the reference's order among equal scores IS the input order -- the library's tie rule
+    ng = int(r.choice([1, 5, 100, 400]))
+    sizes = r.integers(1, 17, ng)
+    gid = np.repeat(np.arange(ng), sizes).astype(np.float32); n2 = gid.size
+    perm2 = r.permutation(n2)
+    gid = gid[perm2]
+    lab2 = (r.uniform(size=n2) < 0.4).astype(np.float32)
+    sc2 = (np.round(r.uniform(0, 1, n2) * int(r.choice([2, 4, 8]))) / 8).astype(np.float32)
+    prob2 = np.stack([1 - sc2, sc2], 1).astype(np.float32)
+    m_ref, eff_ref = O.map_score(prob2, lab2, gid)
+    rr_ref, _ = O.mrr_score(prob2, lab2, gid)
+    m, rr, eff = capi.rank_map_mrr(dev(prob2), dev(lab2), dev(gid))
+    chk(eff == eff_ref and (bits(m) == bits(m_ref) or (np.isnan(m) and np.isnan(m_ref))) and
+        (bits(rr) == bits(rr_ref) or (np.isnan(rr) and np.isnan(rr_ref))), "tied, groups <= 16: seed %d n %d: %r %r vs %r %r" % (seed, n2, m, rr, m_ref, rr_ref))
     # Embed
     M = int(r.choice([1, 40, 2000, 4000, 4097, 30000])); K = int(r.choice([2, 50, 3000, 20000])); N = int(r.choice([1, 50, 64, 65, 300]))
     idx = r.integers(0, K, M)
