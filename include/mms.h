@@ -324,6 +324,20 @@ size_t mms_triplet_workspace_bytes(int N);
  * for bit even when tied scores carry different labels).
  * ------------------------------------------------------------------------- */
 
+/* Order of EQUAL scores that carry different labels (MAP / MRR / AUC; per calling thread).
+ *   MMS_RANK_TIES_INPUT_ORDER (default): ties keep the input order -- also what libstdc++ does in buckets of at
+ *       most 16 items.
+ *   MMS_RANK_TIES_LIBSTDCXX: the order a libstdc++ build of the reference leaves them in -- buckets of more than
+ *       16 items that contain such a tie are re-sorted by a step-by-step restatement of libstdc++'s std::sort
+ *       (csrc/libstdcxx_sort.h: introsort with median-of-three partitioning, heap-sort fallback, final insertion
+ *       sort; checked against the real std::sort by tests/test_libstdcxx_sort.py) on the bucket's items in their
+ *       original order.  Sequential, one lane per bucket: microseconds for a candidate group, milliseconds for
+ *       AUC's single bucket of thousands of items; buckets without such a tie cost one extra pass. */
+#define MMS_RANK_TIES_INPUT_ORDER 0
+#define MMS_RANK_TIES_LIBSTDCXX 1
+int mms_set_rank_tie_mode(int mode);
+int mms_get_rank_tie_mode(void);
+
 /* Replaces MAPLayer<float>::Forward_cpu (src/caffe/layers/map_layer.cpp:41-100) and
  * MRRLayer<float>::Forward_cpu (src/caffe/layers/mrr_layer.cpp:38-79).
  * prob (n, fixed_axis+1): the score of item i is prob[i*(fixed_axis+1)+fixed_axis];

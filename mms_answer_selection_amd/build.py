@@ -21,7 +21,7 @@ LIB = os.path.join(HERE, "libmms_hip.so")
 LAYER_LIB = os.path.join(HERE, "libmms_caffe.so")
 
 HIP_SOURCES = ["mms_abi.hip", "simcross_elementwise.hip", "bilinear.hip", "pairrank.hip", "ranking.hip", "embed.hip", "f64_paths.hip"]
-HIP_HEADERS = ["mms_common.h", "euclid_math.h"]
+HIP_HEADERS = ["mms_common.h", "euclid_math.h", "libstdcxx_sort.h"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",

@@ -58,6 +58,8 @@ _SIGNATURES = {
     "mms_dot_f64": (_i, [_i, _vp, _vp, _vp, _vp]),
     "mms_set_f16_distance_mode": (_i, [_i]),
     "mms_get_f16_distance_mode": (_i, []),
+    "mms_set_rank_tie_mode": (_i, [_i]),
+    "mms_get_rank_tie_mode": (_i, []),
     "mms_set_loss_sum_mode": (_i, [_i]),
     "mms_get_loss_sum_mode": (_i, []),
     "mms_set_triplet_finish_mode": (_i, [_i]),
@@ -403,6 +405,13 @@ def set_f16_distance_mode(mode):
     ~1e-6 relative, no ordered chain.  Per calling thread; fp16-storage entry points only."""
     m = {"ordered": 0, "tree": 1}[mode] if isinstance(mode, str) else int(mode)
     check(lib().mms_set_f16_distance_mode(m), "mms_set_f16_distance_mode")
+
+
+def set_rank_tie_mode(mode):
+    """'input' (default): equal scores keep the input order; 'libstdcxx': the order libstdc++'s std::sort leaves them in
+    (include/mms.h: MMS_RANK_TIES_*)."""
+    m = {"input": 0, "libstdcxx": 1}[mode] if isinstance(mode, str) else int(mode)
+    check(lib().mms_set_rank_tie_mode(m), "mms_set_rank_tie_mode")
 
 
 def set_loss_sum_mode(mode):

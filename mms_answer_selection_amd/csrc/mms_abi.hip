@@ -72,6 +72,8 @@ int triplet_finish_mode();
 void set_triplet_finish_mode(int m);
 int loss_sum_mode();
 void set_loss_sum_mode(int m);
+int rank_tie_mode();
+void set_rank_tie_mode(int m);
 int f16_distance_mode();
 void set_f16_distance_mode(int m);
 // f64_paths.hip
@@ -468,6 +470,13 @@ int mms_set_loss_sum_mode(int mode) {
   return MMS_OK;
 }
 int mms_get_loss_sum_mode(void) { return loss_sum_mode(); }
+
+int mms_set_rank_tie_mode(int mode) {
+  if (mode != MMS_RANK_TIES_INPUT_ORDER && mode != MMS_RANK_TIES_LIBSTDCXX) return MMS_ERR_INVALID_ARG;
+  set_rank_tie_mode(mode);
+  return MMS_OK;
+}
+int mms_get_rank_tie_mode(void) { return rank_tie_mode(); }
 int mms_set_f16_distance_mode(int mode) {
   if (mode != MMS_F16_DISTANCE_ORDERED && mode != MMS_F16_DISTANCE_TREE) return MMS_ERR_INVALID_ARG;
   set_f16_distance_mode(mode);

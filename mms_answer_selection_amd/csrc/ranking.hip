@@ -24,9 +24,15 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include "libstdcxx_sort.h"
 #include "mms_common.h"
 
 namespace mms {
+
+// How EQUAL scores with different labels are ordered (include/mms.h: mms_set_rank_tie_mode); per calling thread.
+static thread_local int t_rank_ties = MMS_RANK_TIES_INPUT_ORDER;
+int rank_tie_mode() { return t_rank_ties; }
+void set_rank_tie_mode(int m) { t_rank_ties = m; }
 
 __device__ __forceinline__ unsigned desc_bits(float s) {
   unsigned u = __float_as_uint(s);
@@ -83,6 +89,15 @@ __device__ __forceinline__ void rank_bucket_at(int i, int n, const unsigned long
     if (mrr_rank >= 0 && zero) { fl |= 2; rank_out[i] = mrr_rank; }
   }
   flags[i] = fl;
+}
+__global__ __launch_bounds__(256) void rank_bucket_pos_kernel(int n,
+                                                              const unsigned long long* __restrict__ keys,
+                                                              const float* __restrict__ lab_pos,
+                                                              float* __restrict__ ap_out,
+                                                              int* __restrict__ rank_out,
+                                                              int* __restrict__ flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) rank_bucket_at<true>(i, n, keys, nullptr, lab_pos, ap_out, rank_out, flags);
 }
 __global__ __launch_bounds__(256) void rank_bucket_kernel(int n,
                                                           const unsigned long long* __restrict__ keys,
@@ -183,7 +198,7 @@ __device__ __forceinline__ void auc_fold_wave(int lane, int n, const unsigned* v
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = base + 64 * u + lane;
-      nxt[u] = label[vals[i < n ? i : n - 1]];
+      nxt[u] = vals ? label[vals[i < n ? i : n - 1]] : label[i < n ? i : n - 1];   // vals == nullptr: labels by position
     }
   };
   fetch(0);
@@ -215,6 +230,90 @@ __global__ __launch_bounds__(64) void auc_fold_kernel(int n, const unsigned* __r
                                                       const float* __restrict__ label, int has_ignore,
                                                       int ignore_label, float* __restrict__ auc_out) {
   auc_fold_wave(threadIdx.x, n, vals, label, has_ignore, ignore_label, auc_out);
+}
+
+// ---- MMS_RANK_TIES_LIBSTDCXX: the order a libstdc++ build of the reference leaves EQUAL scores in -----------------
+// std::sort is not stable; where equal scores carry different labels the metrics depend on what that algorithm
+// does.  Up to 16 items it is a stable insertion sort (= the stable order above).  For larger buckets with such a
+// tie the bucket is re-sorted by ONE lane running libstdcxx_sort.h on the bucket's items in their original
+// (push_back) order -- sequential by nature, hence opt-in: a few microseconds for a TREC-QA candidate group, but
+// milliseconds for AUC's single bucket of thousands of items.
+constexpr int kTieLds = 4096;
+__global__ __launch_bounds__(256) void rank_ties_detect_kernel(int n, const unsigned long long* __restrict__ keys,
+                                                               const unsigned* __restrict__ vals,
+                                                               const float* __restrict__ label,
+                                                               float* __restrict__ lab_pos, int* __restrict__ work,
+                                                               int* __restrict__ nwork) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  lab_pos[i] = label[vals[i]];
+  const unsigned g = (unsigned)(keys[i] >> 32);
+  if (i != 0 && (unsigned)(keys[i - 1] >> 32) == g) return;
+  int m = 0;
+  bool cross = false;
+  for (int p = i; p < n && (unsigned)(keys[p] >> 32) == g; ++p) {
+    ++m;
+    if (p > i && (unsigned)keys[p] == (unsigned)keys[p - 1] && (int)label[vals[p]] != (int)label[vals[p - 1]]) cross = true;
+  }
+  if (cross && m > 16) {
+    const int w = atomicAdd(nwork, 1);
+    work[2 * w] = i;
+    work[2 * w + 1] = m;
+  }
+}
+__global__ __launch_bounds__(64) void rank_ties_emulate_kernel(int stride, int offset, int inner,
+                                                               const float* __restrict__ prob,
+                                                               const float* __restrict__ label,
+                                                               const unsigned* __restrict__ vals,
+                                                               const int* __restrict__ work,
+                                                               const int* __restrict__ nwork, int skip_ignored,
+                                                               int ignore_label, float* __restrict__ lab_pos,
+                                                               SortItem* __restrict__ g_items,
+                                                               unsigned* __restrict__ g_idx) {
+  __shared__ SortItem s_items[kTieLds];
+  __shared__ unsigned s_idx[kTieLds];
+  if (threadIdx.x != 0) return;                      // the algorithm is sequential: one lane per bucket
+  const int cnt = *nwork;
+  for (int w = blockIdx.x; w < cnt; w += gridDim.x) {
+    const int start = work[2 * w], m = work[2 * w + 1];
+    SortItem* it = m <= kTieLds ? s_items : g_items + start;
+    unsigned* ix = m <= kTieLds ? s_idx : g_idx + start;
+    // the bucket in push_back order = ascending item index (a heap sort of the indices: they are distinct)
+    for (int j = 0; j < m; ++j) ix[j] = vals[start + j];
+    for (int root0 = m / 2 - 1; root0 >= 0; --root0) {
+      int root = root0;
+      const unsigned v = ix[root];
+      for (int c = 2 * root + 1; c < m; c = 2 * root + 1) {
+        if (c + 1 < m && ix[c + 1] > ix[c]) ++c;
+        if (ix[c] <= v) break;
+        ix[root] = ix[c]; root = c;
+      }
+      ix[root] = v;
+    }
+    for (int end = m - 1; end > 0; --end) {
+      const unsigned v = ix[end];
+      ix[end] = ix[0];
+      int root = 0;
+      for (int c = 1; c < end; c = 2 * root + 1) {
+        if (c + 1 < end && ix[c + 1] > ix[c]) ++c;
+        if (ix[c] <= v) break;
+        ix[root] = ix[c]; root = c;
+      }
+      ix[root] = v;
+    }
+    int used = 0;
+    for (int j = 0; j < m; ++j) {
+      const int idx = (int)ix[j], lab = (int)label[idx];
+      if (skip_ignored && lab == ignore_label) continue;                        // auc_layer.cpp:68-70: never pushed
+      const int o = idx / inner, jj = idx - o * inner;
+      it[used].key = prob[(size_t)o * stride + (size_t)offset * inner + jj];
+      it[used].lab = lab;
+      ++used;
+    }
+    libstdcxx_sort(it, used);
+    for (int j = 0; j < used; ++j) lab_pos[start + j] = (float)it[j].lab;
+    for (int j = used; j < m; ++j) lab_pos[start + j] = (float)ignore_label;    // skipped items: behind the rest, still skipped
+  }
 }
 
 // ---- the whole metric in ONE workgroup for small inputs (a mini-batch's worth of candidates) ----------------------
@@ -296,7 +395,7 @@ __global__ void rank_accuracy_finish_kernel(int blocks, int count, const unsigne
 
 // ------------------------------- workspace layout ---------------------------
 struct RankWs {
-  size_t keys0, keys1, vals0, vals1, ap, rr, flags, temp, total;
+  size_t keys0, keys1, vals0, vals1, ap, rr, flags, labpos, work, nwork, titems, tidx, temp, total;
 };
 static RankWs rank_ws(int n) {
   RankWs w{};
@@ -305,6 +404,8 @@ static RankWs rank_ws(int n) {
   w.keys0 = take((size_t)n * 8); w.keys1 = take((size_t)n * 8);
   w.vals0 = take((size_t)n * 4); w.vals1 = take((size_t)n * 4);
   w.ap = take((size_t)n * 4); w.rr = take((size_t)n * 4); w.flags = take((size_t)n * 4);
+  w.labpos = take((size_t)n * 4); w.work = take((size_t)n * 8); w.nwork = take(256);      // MMS_RANK_TIES_LIBSTDCXX
+  w.titems = take((size_t)n * sizeof(SortItem)); w.tidx = take((size_t)n * 4);
   w.temp = o;
   w.total = o + (size_t)n * 8 + (4u << 20);   // generous bound for rocPRIM's scratch; checked at run time
   return w;
@@ -330,7 +431,8 @@ static int sort_pairs(const RankWs& lay, char* base, size_t ws_bytes, int n, uns
 int rank_map_mrr(int n, int fixed_axis, const float* prob, const float* label, const float* group,
                  float* map_out, float* mrr_out, int* effective, void* ws, size_t ws_bytes,
                  hipStream_t s) {
-  if (n > 0 && n <= kRankSmall) {                    // evaluation-sized: one workgroup, one launch
+  const bool libstd = rank_tie_mode() == MMS_RANK_TIES_LIBSTDCXX;
+  if (n > 0 && n <= kRankSmall && !libstd) {         // evaluation-sized: one workgroup, one launch
     hipLaunchKernelGGL(rank_small_kernel<0>, dim3(1), dim3(1024), 0, s, n, fixed_axis + 1, fixed_axis, 1, prob,
                        label, group, 0, 0, map_out, mrr_out, effective);
     return launch_status();
@@ -347,6 +449,19 @@ int rank_map_mrr(int n, int fixed_axis, const float* prob, const float* label, c
   if (rc != MMS_OK) return rc;
   auto* keys = reinterpret_cast<unsigned long long*>(base + lay.keys1);
   auto* vals = reinterpret_cast<unsigned*>(base + lay.vals1);
+  if (libstd) {
+    auto* labpos = reinterpret_cast<float*>(base + lay.labpos);
+    auto* work = reinterpret_cast<int*>(base + lay.work);
+    auto* nwork = reinterpret_cast<int*>(base + lay.nwork);
+    if (hipMemsetAsync(nwork, 0, sizeof(int), s) != hipSuccess) return MMS_ERR_LAUNCH;
+    hipLaunchKernelGGL(rank_ties_detect_kernel, dim3(grid), dim3(256), 0, s, n, keys, vals, label, labpos, work, nwork);
+    hipLaunchKernelGGL(rank_ties_emulate_kernel, dim3(256), dim3(64), 0, s, fixed_axis + 1, fixed_axis, 1, prob, label,
+                       vals, work, nwork, 0, 0, labpos, reinterpret_cast<SortItem*>(base + lay.titems),
+                       reinterpret_cast<unsigned*>(base + lay.tidx));
+    hipLaunchKernelGGL(rank_bucket_pos_kernel, dim3(grid), dim3(256), 0, s, n, keys, labpos,
+                       reinterpret_cast<float*>(base + lay.ap), reinterpret_cast<int*>(base + lay.rr),
+                       reinterpret_cast<int*>(base + lay.flags));
+  } else
   hipLaunchKernelGGL(rank_bucket_kernel, dim3(grid), dim3(256), 0, s, n, keys, vals, label,
                      reinterpret_cast<float*>(base + lay.ap), reinterpret_cast<int*>(base + lay.rr),
                      reinterpret_cast<int*>(base + lay.flags));
@@ -359,7 +474,8 @@ int rank_map_mrr(int n, int fixed_axis, const float* prob, const float* label, c
 // n = outer * inner items; dim = channels * inner floats per outer index
 int rank_auc(int n, int dim, int fixed_axis, int inner, const float* prob, const float* label, int has_ignore,
              int ignore_label, float* auc_out, void* ws, size_t ws_bytes, hipStream_t s) {
-  if (n > 0 && n <= kRankSmall) {
+  const bool libstd = rank_tie_mode() == MMS_RANK_TIES_LIBSTDCXX;
+  if (n > 0 && n <= kRankSmall && !libstd) {
     hipLaunchKernelGGL(rank_small_kernel<1>, dim3(1), dim3(1024), 0, s, n, dim, fixed_axis, inner, prob, label,
                        static_cast<const float*>(nullptr), has_ignore, ignore_label, auc_out,
                        static_cast<float*>(nullptr), static_cast<int*>(nullptr));
@@ -376,6 +492,21 @@ int rank_auc(int n, int dim, int fixed_axis, int inner, const float* prob, const
                      reinterpret_cast<unsigned*>(base + lay.vals0));
   int rc = sort_pairs(lay, base, ws_bytes, n, 32u, s);
   if (rc != MMS_OK) return rc;
+  if (libstd) {
+    auto* keys = reinterpret_cast<unsigned long long*>(base + lay.keys1);
+    auto* vals = reinterpret_cast<unsigned*>(base + lay.vals1);
+    auto* labpos = reinterpret_cast<float*>(base + lay.labpos);
+    auto* work = reinterpret_cast<int*>(base + lay.work);
+    auto* nwork = reinterpret_cast<int*>(base + lay.nwork);
+    if (hipMemsetAsync(nwork, 0, sizeof(int), s) != hipSuccess) return MMS_ERR_LAUNCH;
+    hipLaunchKernelGGL(rank_ties_detect_kernel, dim3(grid), dim3(256), 0, s, n, keys, vals, label, labpos, work, nwork);
+    hipLaunchKernelGGL(rank_ties_emulate_kernel, dim3(1), dim3(64), 0, s, dim, fixed_axis, inner, prob, label, vals,
+                       work, nwork, has_ignore, ignore_label, labpos, reinterpret_cast<SortItem*>(base + lay.titems),
+                       reinterpret_cast<unsigned*>(base + lay.tidx));
+    hipLaunchKernelGGL(auc_fold_kernel, dim3(1), dim3(64), 0, s, n, static_cast<const unsigned*>(nullptr), labpos,
+                       has_ignore, ignore_label, auc_out);
+    return launch_status();
+  }
   hipLaunchKernelGGL(auc_fold_kernel, dim3(1), dim3(64), 0, s, n,
                      reinterpret_cast<unsigned*>(base + lay.vals1), label, has_ignore, ignore_label,
                      auc_out);

@@ -135,6 +135,46 @@ def test_cross_label_ties_in_groups_of_at_most_16_follow_the_reference(seed, ora
     assert same_bits(rr, rr_ref) or (np.isnan(rr) and np.isnan(rr_ref)), (rr, rr_ref)
 
 
+@pytest.mark.parametrize("n,ngroups,levels", [(300, 6, 4), (1517, 70, 8), (1517, 5, 3), (6000, 40, 16), (700, 1, 5), (513, 30, 2)])
+def test_cross_label_ties_libstdcxx_mode(n, ngroups, levels, oracle, hiplib):
+    """MMS_RANK_TIES_LIBSTDCXX: candidate groups of MORE than 16 items with equal scores across labels -- MAP, MRR and
+    AUC carry the bits of the oracle build (g++'s std::sort), where the default input-order rule does not."""
+    from mms_answer_selection_amd import capi
+    r = rng(n + ngroups + levels)
+    group = r.integers(0, ngroups, n).astype(np.float32) - 1
+    label = (r.uniform(size=n) < 0.35).astype(np.float32)
+    score = (np.round(r.uniform(0, 1, n) * levels) / levels).astype(np.float32)
+    prob = np.stack([1 - score, score], 1).astype(np.float32)
+    m_ref, eff_ref = oracle.map_score(prob, label, group)
+    rr_ref, _ = oracle.mrr_score(prob, label, group)
+    auc_ref = oracle.auc_score(prob, label)
+    lab_ign = label.copy(); lab_ign[r.uniform(size=n) < 0.2] = 7.0
+    auc_ign_ref = oracle.auc_score_nd(prob, lab_ign, axis=1, fixed_axis=1, ignore_label=7)
+    capi.set_rank_tie_mode("libstdcxx")
+    try:
+        m, rr, eff = capi.rank_map_mrr(dev(prob), dev(label), dev(group))
+        auc = capi.rank_auc(dev(prob), dev(label))
+        auc_ign = capi.rank_auc(dev(prob), dev(lab_ign), ignore_label=7)
+    finally:
+        capi.set_rank_tie_mode("input")
+    assert eff == eff_ref
+    assert same_bits(m, m_ref), (m, m_ref)
+    assert same_bits(rr, rr_ref), (rr, rr_ref)
+    assert same_bits(auc, auc_ref), (auc, auc_ref)
+    assert same_bits(auc_ign, auc_ign_ref), (auc_ign, auc_ign_ref)
+    assert hiplib.mms_set_rank_tie_mode(9) == 1 and hiplib.mms_get_rank_tie_mode() == 0
+    # distinct scores: the mode changes nothing
+    score2 = ((r.permutation(n) + 0.5) / n).astype(np.float32)
+    prob2 = np.stack([1 - score2, score2], 1).astype(np.float32)
+    base = capi.rank_map_mrr(dev(prob2), dev(label), dev(group))
+    capi.set_rank_tie_mode("libstdcxx")
+    try:
+        again = capi.rank_map_mrr(dev(prob2), dev(label), dev(group))
+    finally:
+        capi.set_rank_tie_mode("input")
+    assert same_bits(base[0], again[0]) and same_bits(base[1], again[1]) and base[2] == again[2]
+
+
 def test_ties_with_equal_labels_are_order_independent(oracle, hiplib):
     """Equal scores: the reference's order is implementation-defined (unstable sort);
     when the tied items share a label every order gives the same metric."""

@@ -55,6 +55,18 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     m, rr, eff = capi.rank_map_mrr(dev(prob2), dev(lab2), dev(gid))
     chk(eff == eff_ref and (bits(m) == bits(m_ref) or (np.isnan(m) and np.isnan(m_ref))) and
         (bits(rr) == bits(rr_ref) or (np.isnan(rr) and np.isnan(rr_ref))), "tied, groups <= 16: seed %d n %d: %r %r vs %r %r" % (seed, n2, m, rr, m_ref, rr_ref))
+    # TIED scores across labels in groups of any size, MMS_RANK_TIES_LIBSTDCXX: the oracle build's order (g++'s std::sort)
+    n3 = int(r.choice([40, 600, 1517, 5000])); g3 = r.integers(0, max(1, n3 // int(r.choice([5, 30, 300]))), n3).astype(np.float32)
+    lab3 = (r.uniform(size=n3) < 0.4).astype(np.float32)
+    sc3 = (np.round(r.uniform(0, 1, n3) * int(r.choice([1, 3, 10, 50]))) / 50).astype(np.float32)
+    prob3 = np.stack([1 - sc3, sc3], 1).astype(np.float32)
+    m_ref, eff_ref = O.map_score(prob3, lab3, g3); rr_ref, _ = O.mrr_score(prob3, lab3, g3); au_ref = O.auc_score(prob3, lab3)
+    capi.set_rank_tie_mode("libstdcxx")
+    m, rr, eff = capi.rank_map_mrr(dev(prob3), dev(lab3), dev(g3)); au = capi.rank_auc(dev(prob3), dev(lab3))
+    capi.set_rank_tie_mode("input")
+    same = lambda x, y: bits(x) == bits(y) or (np.isnan(x) and np.isnan(y))
+    chk(eff == eff_ref and same(m, m_ref) and same(rr, rr_ref) and same(au, au_ref),
+        "tied, libstdcxx mode: seed %d n %d: %r %r %r vs %r %r %r" % (seed, n3, m, rr, au, m_ref, rr_ref, au_ref))
     # Embed
     M = int(r.choice([1, 40, 2000, 4000, 4097, 30000])); K = int(r.choice([2, 50, 3000, 20000])); N = int(r.choice([1, 50, 64, 65, 300]))
     idx = r.integers(0, K, M)
