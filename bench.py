@@ -106,7 +106,7 @@ class Batches:
         if path == "cosine":
             self.n0 = torch.empty(ring, N_PAIRS, 1, device="cuda")
             self.n1 = torch.empty(ring, N_PAIRS, 1, device="cuda")
-        if path == "triplet":
+        if path in ("triplet", "triplet_noloss"):
             self.an = mk(ring, N_PAIRS, 1, DIM) * 0.4
             self.y = (torch.rand(ring, N_PAIRS, 1, device="cuda", generator=g) < 0.8).float()
             self.dan = torch.empty_like(self.a)
@@ -127,6 +127,10 @@ def make_step(capi, bt, path):
         def step(i, top):
             capi.simcross_forward(1, bt.q[i], bt.a[i], top)
             capi.simcross_backward(1, bt.q[i], bt.a[i], top, bt.dT[i], bt.dq[i], bt.da[i])
+    elif path == "triplet_noloss":     # loss = NULL: scores and gradients only (the scalar is a display value)
+        def step(i, top):
+            capi.triplet_euclid_step(bt.q[i], bt.a[i], bt.an[i], bt.y[i], top.view(N_PAIRS, 1),
+                                     bt.sneg[i], None, bt.dq[i], bt.da[i], bt.dan[i], margin=0.05)
     else:
         def step(i, top):
             capi.triplet_euclid_step(bt.q[i], bt.a[i], bt.an[i], bt.y[i], top.view(N_PAIRS, 1),
@@ -879,7 +883,8 @@ def variants(torch, capi, args):
                              ("fused_cold_reference_rounding_bwd", "fused", 64),
                              ("layers_cold", "layers", 64), ("layers_warm", "layers", 1),
                              ("cosine_fused_cold", "cosine", 64),
-                             ("triplet_cold", "triplet", 48)):
+                             ("triplet_cold", "triplet", 48),
+                             ("triplet_cold_without_loss_scalar", "triplet_noloss", 48)):
         ref_mode = name.endswith("reference_rounding_bwd")
         if path == args.path and ((ring == 1) == args.warm) and not ref_mode:
             continue
@@ -922,7 +927,7 @@ def variants(torch, capi, args):
         us = median(ts)
         pairs = N_PAIRS
         res[name] = {"us_per_step": us, "pairs_per_s": pairs / (us * 1e-6)}
-        if path != "triplet":
+        if not path.startswith("triplet"):
             res[name]["frac_hbm_unfused_bytes"] = B_UNFUSED / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
         del bt, graphs
         torch.cuda.empty_cache()

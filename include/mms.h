@@ -285,6 +285,8 @@ size_t mms_pairrank_workspace_bytes(int count);
  * the (bit-exact) per-triplet terms, hence within 1e-5 of the reference's value wherever the reference's fp32
  * running sum is itself that close to the exact mean (for thousands of near-constant terms it drifts by 1-2e-5:
  * DESIGN.md 5); bit-identical to the reference's in MMS_LOSS_SUM_REFERENCE mode (above).
+ * `loss` may be NULL: the scalar (a display value: no gradient depends on it) is then not reduced at all -- 7.6
+ * instead of 9.6 us of kernel time at 4096 x 300.
  * loss_partials: mms_triplet_workspace_bytes(N) bytes of device scratch.
  * ------------------------------------------------------------------------- */
 /* How the loss scalar of the fused step is summed (per calling thread):

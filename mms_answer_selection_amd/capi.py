@@ -263,7 +263,7 @@ def triplet_euclid_step(q, a_pos, a_neg, y, s_pos, s_neg, loss, dq, da_pos, da_n
     check(lib().mms_triplet_euclid_step_f32(
         N, D, float(margin), float(loss_weight), _ptr(q, "q"), _ptr(a_pos, "a_pos"),
         _ptr(a_neg, "a_neg"), _ptr(y, "y"), _ptr(s_pos, "s_pos"), _ptr(s_neg, "s_neg"),
-        _ptr(loss, "loss"), _ptr(dq, "dq"), _ptr(da_pos, "da_pos"), _ptr(da_neg, "da_neg"),
+        _ptr(loss, "loss", True), _ptr(dq, "dq"), _ptr(da_pos, "da_pos"), _ptr(da_neg, "da_neg"),
         wsp, wsb, _stream()), "mms_triplet_euclid_step_f32")
 
 

@@ -352,7 +352,7 @@ int mms_triplet_euclid_step_f32(int N, int D, float margin, float loss_weight, c
                                 float* da_neg, void* workspace, size_t workspace_bytes,
                                 void* stream) {
   if (N <= 0 || D <= 0 || (long long)N * D > 0x7fffffffLL) return MMS_ERR_INVALID_ARG;
-  if (!q || !a_pos || !a_neg || !y || !s_pos || !s_neg || !loss || !dq || !da_pos || !da_neg)
+  if (!q || !a_pos || !a_neg || !y || !s_pos || !s_neg || !dq || !da_pos || !da_neg)   // loss may be NULL
     return MMS_ERR_INVALID_ARG;
   return triplet_euclid_step(N, D, margin, loss_weight, q, a_pos, a_neg, y, s_pos, s_neg, loss,
                              dq, da_pos, da_neg, workspace, workspace_bytes, as_stream(stream));

@@ -901,7 +901,7 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
     // terms are summed by a second, one-workgroup launch.
     const unsigned ngrp = (grid + kTicketGroup - 1) / kTicketGroup;
     unsigned long long* tk = (triplet_finish_mode() != MMS_TRIPLET_FINISH_INLAUNCH || ngrp > (unsigned)kTicketTop ||
-                              loss_sum_mode() == MMS_LOSS_SUM_REFERENCE)
+                              loss_sum_mode() == MMS_LOSS_SUM_REFERENCE || loss == nullptr)
                                  ? nullptr : next_ticket_slot();
     int lg = 0;
     while (((long long)1 << lg) < (long long)N) ++lg;
@@ -936,6 +936,7 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
                        dim3(kTripThreads), lds, s, N, D, margin, s0, s1, q, ap, an, y, s_pos,
                        s_neg, partials, dq, dap, dan, hge);
   }
+  if (loss == nullptr) return launch_status();     // the caller does not want the scalar: no reduction at all
   if (loss_sum_mode() == MMS_LOSS_SUM_REFERENCE)   // nparts == N on every path: one term per triplet
     hipLaunchKernelGGL(loss_running_sum_kernel, dim3(1), dim3(256), 0, s, partials, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, N, loss);

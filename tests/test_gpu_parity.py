@@ -636,6 +636,24 @@ def test_triplet_step_many_launches_and_graph_replay(hiplib):
     _many_launches(capi, q, ap, an, y, ws, mk, first, two)
 
 
+def test_triplet_step_without_the_loss_scalar(oracle, hiplib):
+    """loss = NULL: scores and gradients as always, no reduction of the display scalar (include/mms.h)."""
+    from mms_answer_selection_amd import capi
+    for (N, D) in ((4095, 300), (77, 52)):
+        g = torch.Generator(device="cuda").manual_seed(N)
+        q = torch.randn(N, 1, D, device="cuda", generator=g) * 0.4
+        ap = q + 0.1 * torch.randn(N, 1, D, device="cuda", generator=g)
+        an = torch.randn(N, 1, D, device="cuda", generator=g) * 0.4
+        y = torch.ones(N, 1, device="cuda")
+        mk = lambda: dict(s_pos=nan_like((N, 1)), s_neg=nan_like((N, 1)), dq=nan_like((N, 1, D)),
+                          da_pos=nan_like((N, 1, D)), da_neg=nan_like((N, 1, D)))
+        a, b = mk(), mk()
+        capi.triplet_euclid_step(q, ap, an, y, loss=nan_like((1,)), margin=0.05, **a)
+        capi.triplet_euclid_step(q, ap, an, y, loss=None, margin=0.05, **b)
+        for k in a:
+            assert_bitexact(host(b[k]), host(a[k]), k)
+
+
 def test_triplet_step_inlaunch_loss_domain(hiplib):
     """In-launch mode sums the terms as integers in units of 2^-S: a term of 2^10 or more (a margin or labels in
     the hundreds) cannot be carried and the loss must come out NaN, not wrong; scores and gradients are
