@@ -1067,6 +1067,14 @@ __global__ __launch_bounds__(512) void bilinear_pair_bwd_kernel(
       va[u] = an[(size_t)min(row, W2 - 1) * D + min(c, D - 1)];
       vt[u] = dT[(size_t)min(row, W1 - 1) * W2 + min(c, W2 - 1)];
     }
+    // W_m's image is requested HERE, with the other three: behind the first LDS writes it was a second, exposed
+    // memory round trip in a workgroup whose whole life is ~10 us
+    float vw[NEW];
+#pragma unroll
+    for (int u = 0; u < NEW; ++u) {
+      const int e = NT * u + t, row = e / FB_LS, c = e - row * FB_LS;
+      vw[u] = Wm[(size_t)min(row, D - 1) * D + min(c, D - 1)];
+    }
 #pragma unroll
     for (int u = 0; u < NE; ++u) {
       const int e = NT * u + t, row = e / FB_LS, c = e - row * FB_LS;
@@ -1077,12 +1085,6 @@ __global__ __launch_bounds__(512) void bilinear_pair_bwd_kernel(
         us[e] = 0.f;                                   // rows / columns no tile writes must read as zero
         vs[e] = 0.f;
       }
-    }
-    float vw[NEW];
-#pragma unroll
-    for (int u = 0; u < NEW; ++u) {
-      const int e = NT * u + t, row = e / FB_LS, c = e - row * FB_LS;
-      vw[u] = Wm[(size_t)min(row, D - 1) * D + min(c, D - 1)];
     }
 #pragma unroll
     for (int u = 0; u < NEW; ++u) {
