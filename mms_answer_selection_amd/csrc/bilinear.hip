@@ -821,6 +821,18 @@ struct BilinearWs {
 static bool pair_bwd_fits(int N, int W1, int W2, int D, int M) {      // = pair_bwd_eligible (defined with the kernel)
   return W1 <= 48 && W2 <= 48 && D <= 64 && W1 * W2 > 1 && N <= 256 && (long long)N * M <= 65535;
 }
+// The sentence-vector geometry with ONE measure (W1 = W2 = 1, M = 1: BASELINE cfg 3 written as a SimCross layer) IS
+// SimMatrix's arithmetic -- T_n = q_n^T W a_n (+ bias), dW = sum_n dT_n q_n a_n^T, dq_n = dT_n W a_n,
+// da_n = dT_n W^T q_n -- so it takes SimMatrix's panel-GEMM launches (row dot and row scale as epilogues) instead
+// of the generic GEMM + rowdot / rowscale launches: 45 + 136 us -> the SimMatrix figures (recomputing Q.W).
+size_t simmatrix_workspace_bytes(int N, int K1, int K2);
+int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, const float* W, float* top, float* qw,
+                      hipStream_t s, const float* rd_bias);
+int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, const float* W,
+                       const float* top_diff, int ppd, int pd0, int pd1, float* dq, float* da,
+                       float* dW, const float* qw, void* ws, size_t ws_bytes, hipStream_t s);
+static bool bilinear_as_simmatrix(int W1, int W2, int M) { return W1 == 1 && W2 == 1 && M == 1; }
+
 static BilinearWs bilinear_ws(int N, int W1, int W2, int D, int M) {
   BilinearWs w{};
   const size_t u = (size_t)M * N * W1 * D, v = (size_t)M * N * W2 * D;
@@ -834,6 +846,10 @@ static BilinearWs bilinear_ws(int N, int W1, int W2, int D, int M) {
   // per-measure partial products of dQ and of dA (M > 1 only): [M][N*W1][D], [M][N*W2][D]
   w.mpart2_off = w.mpart_off + (M > 1 ? round_up(u * sizeof(float), 256) : 0);
   w.total = w.mpart2_off + (M > 1 ? round_up(v * sizeof(float), 256) : 0);
+  if (bilinear_as_simmatrix(W1, W2, M)) {            // [Q.W, N x D][SimMatrix's own workspace]
+    const size_t sm = round_up((size_t)N * D * sizeof(float), 256) + simmatrix_workspace_bytes(N, D, D);
+    if (sm > w.total) w.total = sm;
+  }
   return w;
 }
 size_t bilinear_workspace_bytes(int N, int W1, int W2, int D, int M) {
@@ -1297,6 +1313,8 @@ int bilinear_forward(int N, int W1, int W2, int D, int M, const float* q, const 
                      hipStream_t s) {
   const BilinearWs lay = bilinear_ws(N, W1, W2, D, M);
   if (!ws || ws_bytes < lay.total) return MMS_ERR_WORKSPACE;
+  if (bilinear_as_simmatrix(W1, W2, M))
+    return simmatrix_forward(N, D, D, q, a, W, top, static_cast<float*>(ws), s, bias);
   // large batches only (evaluation: the 1517 TREC-QA test candidates, 89 -> 59 us): at the training batch of
   // 50 pairs both forms sit at the launch floor and the two small GEMMs are marginally quicker
   if (W1 <= PF_ROWS && W2 <= PF_ROWS && D <= 16 * PF_TD && W1 * W2 > 1 && N >= 512) {
@@ -1392,6 +1410,13 @@ int bilinear_backward(int N, int W1, int W2, int D, int M, const float* q, const
     else
       hipLaunchKernelGGL(dbias_kernel, dim3((per_n + 63) / 64), dim3(256), 0, s, top_diff, N, per_n,
                          dbias);
+  }
+  if (bilinear_as_simmatrix(W1, W2, M)) {
+    // W.diff is OVERWRITTEN by SimCross (:256) where SimMatrix accumulates: start from zero (0 + x = x exactly)
+    if (hipMemsetAsync(dW, 0, sizeof(float) * (size_t)D * D, s) != hipSuccess) return MMS_ERR_LAUNCH;
+    const size_t off = round_up((size_t)N * D * sizeof(float), 256);
+    return simmatrix_backward(N, D, D, q, a, W, top_diff, 1, 1, 1, dq, da, dW, nullptr, base + off,
+                              ws_bytes - off, s);
   }
   // U_nm = dT_nm A_n  (W1 x D x W2) ;  V_nm = dT_nm^T Q_n  (W2 x D x W1)
   if (W1 == 1 && W2 == 1 && M == 1) {
@@ -1489,12 +1514,13 @@ static SimMatrixWs simmatrix_ws(int N, int K1, int K2) {
 size_t simmatrix_workspace_bytes(int N, int K1, int K2) { return simmatrix_ws(N, K1, K2).total; }
 
 int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, const float* W,
-                      float* top, float* qw, hipStream_t s) {
+                      float* top, float* qw, hipStream_t s, const float* rd_bias) {
   // qw = Q W  (:60-61) ; top_i = a_i . qw_i  (:62-64)
   {
     // one launch: the row dot is the product's epilogue
     PanelArgs p = panel_args(N, K2, K1, q, K1, W, K2, qw, K2);
     p.Y = a; p.ldy = K2; p.rowdot = top; p.rd_stride = 1;
+    p.rd_bias = rd_bias;                        // SimCross bilinear's bias (one scalar at W1 = W2 = 1), else null
     if (panel_eligible(p, true)) {
       panel_launch(p, true, s);
       return launch_status();
@@ -1502,7 +1528,7 @@ int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, con
   }
   GemmArgs g = gemm_args(N, K2, K1, q, K1, 1, W, K2, 1, qw, K2);
   gemm_launch(g, 1, s);
-  hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a, qw, nullptr,
+  hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a, qw, rd_bias,
                      top, (long long)N, K2, 1LL);
   return launch_status();
 }

@@ -30,7 +30,7 @@ int embed_bilinear_forward(int N, int W1, int W2, int D, int M, int K, const flo
                            const float* bias, float* top, hipStream_t s);
 size_t simmatrix_workspace_bytes(int N, int K1, int K2);
 int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, const float* W,
-                      float* top, float* qw, hipStream_t s);
+                      float* top, float* qw, hipStream_t s, const float* rd_bias);
 int embed_simcross_forward(int mode, int N, int W1, int W2, int D, int K, const float* index_q,
                            const float* index_a, const float* weight, const float* embed_bias, float* top,
                            float* norm0, float* norm1, hipStream_t s);
@@ -288,7 +288,7 @@ int mms_simmatrix_forward_f32(int N, int K1, int K2, const float* q, const float
   if (N < 0 || K1 <= 0 || K2 <= 0) return MMS_ERR_INVALID_ARG;
   if (N == 0) return MMS_OK;
   if (!q || !a || !W || !top || !qw_scratch) return MMS_ERR_INVALID_ARG;
-  return simmatrix_forward(N, K1, K2, q, a, W, top, qw_scratch, as_stream(stream));
+  return simmatrix_forward(N, K1, K2, q, a, W, top, qw_scratch, as_stream(stream), nullptr);
 }
 
 int mms_simmatrix_backward_f32(int N, int K1, int K2, const float* q, const float* a,

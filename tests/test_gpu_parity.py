@@ -376,6 +376,9 @@ def test_cosine_forward_backward(shape, oracle, hiplib):
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("cfg", [
     (8, 1, 1, 300, 1, False),
+    (2000, 1, 1, 300, 1, True),   # cfg 3 written as a SimCross layer: routed to SimMatrix's panel-GEMM launches
+    (777, 1, 1, 52, 1, True),
+    (130, 1, 1, 301, 1, False),   # ... and its generic fallback (odd width)
     (4, 5, 7, 300, 2, True),
     (2, 40, 40, 50, 4, True),     # network_v4: mesure_count 4, bias_term true
     (3, 9, 4, 33, 3, True),
