@@ -997,7 +997,22 @@ def other_configs(torch, capi):
     out["cfg3_simmatrix_recomputing_backward"] = {
         "us_per_step": us, "pairs_per_s": N / (us * 1e-6), "TFLOPs": flops / us / 1e6,
         "frac_mfma_fp32_peak": flops / (us * 1e-6) / 157.3e12, "bound": "mfma", "dtype": "f32"}
-    del q, a, W, dT, top, scr, dq, da, dW
+
+    # the same arithmetic written as a SimCross layer: dist_mode 2, one measure, W1 = W2 = 1 (bias_term false, like
+    # SimMatrix; with the scalar bias its gradient -- an n-ordered sum of 16384 terms, one dependent chain -- adds ~120 us)
+    q3, a3, W3 = q.view(N, 1, K), a.view(N, 1, K), W.view(1, K, K)
+    t3, dT3 = torch.empty(N, 1, 1, 1, device="cuda"), dT.view(N, 1, 1, 1)
+    dq3, da3, dW3 = torch.empty_like(q3), torch.empty_like(a3), torch.empty_like(W3)
+
+    def cfg3_simcross():
+        capi.simcross_forward(2, q3, a3, t3, W=W3, ws=ws)
+        capi.simcross_backward(2, q3, a3, t3, dT3, dq3, da3, W=W3, bias_term=False, dW=dW3, ws=ws)
+    us = _graph_time(torch, cfg3_simcross, iters=16)
+    out["cfg3_as_simcross_bilinear_16384x1x1x300_M1_fwd_bwd"] = {
+        "us_per_step": us, "pairs_per_s": N / (us * 1e-6), "TFLOPs": flops / us / 1e6,
+        "frac_mfma_fp32_peak": flops / (us * 1e-6) / 157.3e12, "bound": "mfma", "dtype": "f32",
+        "note": "SimCross dist_mode 2 at W1 = W2 = 1, M = 1: SimMatrix's panel-GEMM launches, Q.W recomputed in the backward"}
+    del q, a, W, dT, top, scr, dq, da, dW, q3, a3, W3, t3, dT3, dq3, da3, dW3
     # cfg 1: the driver's training geometry, SimCross bilinear M = 4 with bias (do_trec_qa_clean.py:452-496)
     for (N1, Wd, D1, M1) in ((32, 40, 300, 4), (50, 40, 50, 4)):
         q1, a1 = rnd(N1, Wd, D1), rnd(N1, Wd, D1)

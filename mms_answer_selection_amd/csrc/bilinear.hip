@@ -719,6 +719,38 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x
 // owns 64 consecutive outputs: its four waves each fetch 16 of the next 64 rows (coalesced 256-byte
 // segments) into LDS while wave 0 adds the previous 64 rows in order.  (One thread per output with
 // eight loads per round trip took 66 us at the 1517-candidate test split; this takes ~12.)
+// per_n == 1 (one scalar bias: SimCross bilinear at W1 = W2 = 1, one measure): the chain kernel above runs on ONE
+// lane that fetches its own operands, a memory round trip per 64 terms (300 us at 16384 pairs).  Here the whole
+// wave fetches -- 64 consecutive terms per load, four loads ahead -- and the running sum, wave-uniform, takes them in
+// n order through v_readlane: the dependent add is all that is left (~3 ns per term).
+__global__ __launch_bounds__(64) void dbias_scalar_kernel(const float* __restrict__ top_diff, int N,
+                                                          float* __restrict__ dbias) {
+  const int lane = threadIdx.x;
+  float s = dbias[0];
+  float nx[4];
+  auto fetch = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) nx[u] = top_diff[min(base + 64 * u + lane, N - 1)];
+  };
+  fetch(0);
+  for (int base = 0; base < N; base += 256) {
+    float cur[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cur[u] = nx[u];
+    if (base + 256 < N) fetch(base + 256);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int left = N - (base + 64 * u);
+      if (left >= 64) {
+#pragma unroll
+        for (int l = 0; l < 64; ++l) s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur[u]), l)) + s;
+      } else {
+        for (int l = 0; l < left; ++l) s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur[u]), l)) + s;
+      }
+    }
+  }
+  if (lane == 0) dbias[0] = s;
+}
 __global__ __launch_bounds__(256) void dbias_kernel(const float* __restrict__ top_diff, int N,
                                                     int per_n, float* __restrict__ dbias) {
   constexpr int CH = 64, RPW = CH / 4;
@@ -1404,7 +1436,9 @@ int bilinear_backward(int N, int W1, int W2, int D, int M, const float* q, const
   // dbias first: it depends on nothing the products write
   if (bias_term) {
     const int per_n = M * W1 * W2;
-    if (per_n <= 256)
+    if (per_n == 1)
+      hipLaunchKernelGGL(dbias_scalar_kernel, dim3(1), dim3(64), 0, s, top_diff, N, dbias);
+    else if (per_n <= 256)
       hipLaunchKernelGGL(dbias_chain_kernel, dim3((per_n + 63) / 64), dim3(64), 0, s, top_diff, N, per_n,
                          dbias);
     else
