@@ -5,8 +5,8 @@ Metric (BASELINE.json): QA pairs/sec (fwd+bwd) at batch 4096, 300-d; % HBM roofl
 Workload (cfg 2): SimCross dist_mode 1 (Euclidean), q,a (4096,1,300) fp32 ->
 T (4096,1,1,1), forward + backward with a given top_diff, per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: starts its own N rank processes, launch_ranks)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the driver's form; same ranks)
 
 A "step" is one forward + one backward pass over one 4096-pair batch through the C ABI.  The
 default `--path layers` issues what a Caffe host can issue through the Layer API: one Forward
@@ -217,9 +217,7 @@ def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch --gpus %d with torch.distributed.run (one rank per GPU)" % args.gpus)
+    if world != args.gpus:                   # under a launcher the environment is authoritative
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
@@ -600,6 +598,52 @@ def run(args):
             out["config"]["per_step_gather_variant"] = {
                 "ms_per_step": median(ev1) / K2, "value": world * N_PAIRS * K2 / (median(ev1) * 1e-3),
                 "note": "one all-gather of 4096 scores per rank after every step (16 KiB messages: latency-bound)"}
+
+    # N > 1, the north-star's split: ONE 4096-pair batch divided over the ranks (strong scaling), each rank runs the
+    # Forward and Backward launches on its contiguous 4096/N pairs and the per-pair scores are all-gathered after
+    # every step -- latency-bound by construction (SURVEY 8e "scaling caveat"), reported next to the weak line
+    if world > 1 and not args.no_variants:
+        from mms_answer_selection_amd import sharded
+        lo, hi = sharded.shard_range(N_PAIRS, rank, world)
+        ns = hi - lo
+        K4 = min(K, 256)
+        tops = [torch.empty(ns, 1, 1, 1, device="cuda") for _ in range(2)]
+        fulls = [torch.empty(N_PAIRS, device="cuda") for _ in range(2)]
+        free4 = [torch.cuda.Event() for _ in range(2)]
+        cnt4 = [0]
+
+        def strong_step():
+            i = cnt4[0]
+            cnt4[0] += 1
+            bi, sl = i & 1, i % ring
+            main.wait_event(free4[bi])
+            if ns:
+                qs, as_ = bt.q[sl][lo:hi], bt.a[sl][lo:hi]
+                capi.simcross_forward(1, qs, as_, tops[bi])
+                capi.simcross_backward(1, qs, as_, tops[bi], bt.dT[sl][lo:hi], bt.dq[sl][lo:hi], bt.da[sl][lo:hi])
+            comm.wait_stream(main)
+            with torch.cuda.stream(comm):
+                if args.backend == "nccl":
+                    sharded.all_gather_scores(tops[bi].view(ns), N_PAIRS, out=fulls[bi])
+                else:
+                    fulls[bi].copy_(sharded.all_gather_scores(tops[bi].view(ns).cpu(), N_PAIRS))
+                free4[bi].record(comm)
+
+        def one4(r):
+            for _ in range(K4):
+                strong_step()
+            main.wait_event(free4[0])
+            main.wait_event(free4[1])
+        for _ in range(4):
+            strong_step()
+        ev4, _ = time_regions(torch, dist, world, main, 3, one4)
+        if rank == 0:
+            out["config"]["strong_split_variant"] = {
+                "scaling": "strong", "pairs_total": N_PAIRS, "pairs_per_gpu": ns, "steps": K4,
+                "ms_per_step": median(ev4) / K4, "value": N_PAIRS * K4 / (median(ev4) * 1e-3), "unit": "pairs/s",
+                "note": "ONE 4096-pair batch split over the ranks: Forward + Backward launches on 4096/N pairs per "
+                        "rank, all-gather of the 4096 scores after every step (launched kernel by kernel; "
+                        "%s)" % ("RCCL" if args.backend == "nccl" else "host-staged gloo rehearsal")}
 
     # a SHORT region (the driver's --steps 20) carries a fixed cost of two event packets and one graph boundary
     # (about 9 us: 0.4 us per step at K = 20, nothing at K = 4096); for the record, the same walk over 2048 steps
@@ -1149,5 +1193,41 @@ def other_configs(torch, capi):
     return out
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` typed as is (no torchrun): this process -- which has NOT imported torch and never
+    touches the GPU -- starts one child per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's
+    stdout (the one JSON line) and exits with the worst child's return code.  What it replaces: the reference starts
+    its per-GPU workers from one command too (`caffe train --gpu all`, tools/caffe.cpp:154-227 ->
+    P2PSync::Run, parallel.cpp:421-430).  Children are plain subprocesses (no exec of a process that has
+    initialised the GPU); the torchrun form of the contract keeps working because it sets WORLD_SIZE itself."""
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as sk:                       # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   MMS_BENCH_CHILD="1")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    worst = 0
+    for rc in rcs:
+        if rc != 0:
+            worst = rc if rc > 0 else 128 - rc        # a child killed by a signal reports as the shell does
+            break
+    return worst
+
+
 if __name__ == "__main__":
-    run(parse())
+    _args = parse()
+    if _args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(_args, sys.argv[1:]))
+    run(_args)

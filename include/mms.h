@@ -17,7 +17,9 @@
  *  - Return value: MMS_OK or an MMS_ERR_* code; nothing is launched on error.
  *    (The C++ Layer mirror turns a non-zero code into the reference's
  *    CHECK/LOG(FATAL) abort.)
- *  - Deterministic: no atomics; the same inputs give the same bits every run.
+ *  - Deterministic: the same inputs give the same bits every run.  No floating-point atomics anywhere; the only
+ *    atomics in the library are the INTEGER arrival words of the fused steps' in-launch loss sum (order-free:
+ *    integer addition commutes), which live in the caller's workspace (mms_triplet_workspace_init).
  *  - Numerics: results whose summation order the reference's
  *    own source fixes (Euclidean SimCross forward/backward, PairRankLoss
  *    per-element terms and gradients) are BIT-IDENTICAL to the reference CPU
@@ -36,7 +38,10 @@
 extern "C" {
 #endif
 
-#define MMS_VERSION 100 /* 0.1.0 */
+/* 0.2.0: mms_embed_simcross_forward_f32 gained `embed_bias`, mms_rank_workspace_bytes and the mms_layer_t option
+ * table changed (round 2), the triplet workspace carries the arrival words and must be initialised (round 3).
+ * A host built against another header must refuse to run: compare mms_version() with MMS_VERSION at start-up. */
+#define MMS_VERSION 200
 
 enum {
   MMS_OK = 0,
@@ -287,7 +292,12 @@ size_t mms_pairrank_workspace_bytes(int count);
  * DESIGN.md 5); bit-identical to the reference's in MMS_LOSS_SUM_REFERENCE mode (above).
  * `loss` may be NULL: the scalar (a display value: no gradient depends on it) is then not reduced at all -- 7.6
  * instead of 9.6 us of kernel time at 4096 x 300.
- * loss_partials: mms_triplet_workspace_bytes(N) bytes of device scratch.
+ * workspace: mms_triplet_workspace_bytes(N) bytes of 8-byte-aligned device memory that belongs to this call
+ * sequence alone: its head holds the arrival words of the in-launch loss sum (zero between launches), the rest one
+ * term per triplet.  Call mms_triplet_workspace_init ONCE after allocating it (it zeroes the words, asynchronously
+ * on `stream`) -- and again if a launch that used it died mid-way; a workspace sized for a larger N serves any
+ * smaller one.  Launches that may be in flight together -- two streams, two captured graphs replayed
+ * concurrently -- need a workspace each; nothing about the words is chosen by host state at call or capture time.
  * ------------------------------------------------------------------------- */
 /* How the loss scalar of the fused step is summed (per calling thread):
  *   MMS_TRIPLET_FINISH_INLAUNCH (default): the step is ONE launch.  The per-triplet terms are added as integers in
@@ -314,6 +324,7 @@ int mms_triplet_euclid_step_f32(int N, int D, float margin, float loss_weight,
                                 void* stream);
 
 size_t mms_triplet_workspace_bytes(int N);
+int mms_triplet_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Ranking metrics over the scores (forward only).  These

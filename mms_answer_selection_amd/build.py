@@ -9,6 +9,7 @@ hipcc cross-compiles without a GPU.  Flags that matter for parity:
                       SGPRs at wave launch (gfx940+), so a latency-bound kernel does not
                       begin with a scalar fetch of its argument block.
 """
+import glob
 import os
 import shutil
 import subprocess
@@ -21,7 +22,12 @@ LIB = os.path.join(HERE, "libmms_hip.so")
 LAYER_LIB = os.path.join(HERE, "libmms_caffe.so")
 
 HIP_SOURCES = ["mms_abi.hip", "simcross_elementwise.hip", "bilinear.hip", "pairrank.hip", "ranking.hip", "embed.hip", "f64_paths.hip"]
-HIP_HEADERS = ["mms_common.h", "euclid_math.h", "libstdcxx_sort.h"]
+def _hip_headers():
+    """Every header under csrc/ is a dependency of every .hip object (panel_gemm.h is included by bilinear.hip,
+    euclid_math.h by three sources, ...): found by glob so that a new header cannot be forgotten."""
+    return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")))
+
+
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
@@ -58,8 +64,7 @@ def _compile_one(args):
 def build_hip(force=False, verbose=False):
     """One object per .hip source (compiled in parallel, rebuilt only when stale), then one link."""
     from concurrent.futures import ThreadPoolExecutor
-    hdrs = [os.path.join(CSRC, f) for f in HIP_HEADERS] + [
-        os.path.join(ROOT, "include", "mms.h"), os.path.abspath(__file__)]
+    hdrs = _hip_headers() + [os.path.join(ROOT, "include", "mms.h"), os.path.abspath(__file__)]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"]

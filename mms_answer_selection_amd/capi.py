@@ -35,6 +35,7 @@ _SIGNATURES = {
     "mms_pairrank_forward_f32": (_i, [_i, _f] + [_vp] * 7 + [_sz, _vp]),
     "mms_pairrank_backward_f32": (_i, [_i, _f] + [_vp] * 3 + [_i, _i] + [_vp] * 3),
     "mms_triplet_workspace_bytes": (_sz, [_i]),
+    "mms_triplet_workspace_init": (_i, [_vp, _sz, _vp]),
     "mms_triplet_euclid_step_f32": (_i, [_i, _i, _f, _f] + [_vp] * 11 + [_sz, _vp]),
     "mms_simcross_euclid_forward_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "mms_simcross_euclid_forward_backward_f16": (_i, [_i, _i] + [_vp] * 7),
@@ -80,6 +81,9 @@ class MMSError(RuntimeError):
     pass
 
 
+MMS_VERSION = 200      # include/mms.h
+
+
 def lib():
     """The loaded C-ABI library; raises (never falls back) if it is not built."""
     global _lib
@@ -93,6 +97,9 @@ def lib():
             fn = getattr(l, name)  # AttributeError if the header and library diverge
             fn.restype = res
             fn.argtypes = args
+        if l.mms_version() != MMS_VERSION:            # include/mms.h: a host built against another header must refuse
+            raise MMSError("libmms_hip.so reports ABI version %d, this binding was written for %d: rebuild "
+                           "(python -m mms_answer_selection_amd.build --force)" % (l.mms_version(), MMS_VERSION))
         _lib = l
     return _lib
 
@@ -256,10 +263,44 @@ def pairrank_backward(y, ordered, similar, da, db, top_diff=1.0, propagate_down=
         _ptr(da, "da", True), _ptr(db, "db", True), _stream()), "mms_pairrank_backward_f32")
 
 
+class TripletWorkspace:
+    """The fused step's own scratch: its head holds the arrival words of the in-launch loss sum, which must be zero
+    between launches (include/mms.h), so it is never shared with other entry points' scratch.  Grow-only; a buffer
+    it outgrows is retired, not freed (a captured hipGraph may hold its address); every new buffer is initialised
+    with mms_triplet_workspace_init on the current stream.  `reset()` re-initialises after a failed launch."""
+
+    def __init__(self):
+        self.buf = None
+        self._retired = []
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            if self.buf is not None:
+                self._retired.append(self.buf)
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self.reset()
+        return self.buf.data_ptr(), self.buf.numel()
+
+    def reset(self):
+        if self.buf is not None:
+            check(lib().mms_triplet_workspace_init(self.buf.data_ptr(), self.buf.numel(), _stream()),
+                  "mms_triplet_workspace_init")
+
+
+_default_triplet_ws = {}
+
+
 def triplet_euclid_step(q, a_pos, a_neg, y, s_pos, s_neg, loss, dq, da_pos, da_neg, margin=1.0,
                         loss_weight=1.0, ws=None):
+    """`ws`: a TripletWorkspace; calls that may be in flight together (streams, concurrently replayed graphs) must
+    not share one.  Default: one per device."""
     N, D = q.shape[0], q.shape[-1]
-    wsp, wsb = (ws or _default_ws).get(lib().mms_triplet_workspace_bytes(N), q.device)
+    if ws is None:
+        ws = _default_triplet_ws.setdefault(q.device, TripletWorkspace())
+    if not isinstance(ws, TripletWorkspace):
+        raise TypeError("triplet_euclid_step needs a capi.TripletWorkspace (its arrival words must stay zero "
+                        "between launches; a general Workspace is overwritten by other calls)")
+    wsp, wsb = ws.get(lib().mms_triplet_workspace_bytes(N), q.device)
     check(lib().mms_triplet_euclid_step_f32(
         N, D, float(margin), float(loss_weight), _ptr(q, "q"), _ptr(a_pos, "a_pos"),
         _ptr(a_neg, "a_neg"), _ptr(y, "y"), _ptr(s_pos, "s_pos"), _ptr(s_neg, "s_neg"),

@@ -92,6 +92,17 @@ static void mms_check(int rc, const char* what) {
   CHECK_EQ(rc, (int)MMS_OK) << what << ": " << mms_error_string(rc);
 }
 
+// A Layer host built against one include/mms.h must not run on a libmms_hip.so built from another (argument lists
+// changed between ABI versions): checked once when this library is loaded, fatal like every other CHECK here.
+namespace {
+struct AbiVersionCheck {
+  AbiVersionCheck() {
+    CHECK_EQ(mms_version(), (int)MMS_VERSION) << "libmms_hip.so ABI version differs from the include/mms.h this "
+                                                 "Layer library was compiled against; rebuild both";
+  }
+} g_abi_version_check;
+}  // namespace
+
 // caffe_gpu_dot (src/caffe/util/math_functions.cu): the product is formed on the device, one scalar comes back
 template <typename T, typename F>
 static T gpu_dot_impl(int n, const T* x, const T* y, F fn) {

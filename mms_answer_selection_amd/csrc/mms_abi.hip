@@ -45,6 +45,7 @@ int pairrank_forward(int count, float margin, const float* a, const float* b, co
 int pairrank_backward(int count, float top_diff, const float* y, const float* ordered,
                       const float* similar, float* da, float* db, hipStream_t s);
 size_t triplet_workspace_bytes(int N);
+int triplet_workspace_init(void* ws, size_t ws_bytes, hipStream_t s);
 int triplet_euclid_step(int N, int D, float margin, float loss_weight, const float* q,
                         const float* ap, const float* an, const float* y, float* s_pos,
                         float* s_neg, float* loss, float* dq, float* dap, float* dan, void* ws,
@@ -345,6 +346,10 @@ int mms_pairrank_backward_f32(int count, float top_diff, const float* y, const f
 }
 
 size_t mms_triplet_workspace_bytes(int N) { return N > 0 ? triplet_workspace_bytes(N) : 0; }
+
+int mms_triplet_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+  return triplet_workspace_init(workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
 
 int mms_triplet_euclid_step_f32(int N, int D, float margin, float loss_weight, const float* q,
                                 const float* a_pos, const float* a_neg, const float* y,

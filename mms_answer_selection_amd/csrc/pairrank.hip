@@ -12,6 +12,7 @@
 // is not reproduced -- tests hold it to 1e-5 relative).
 #include <atomic>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 
@@ -26,7 +27,6 @@ int euclid_backward_mode();   // simcross_elementwise.hip
 // the reference's Backward_cpu uses `ordered > 0` (pair_rank_loss_layer.cpp:76), its Backward_gpu kernel
 // `ordered >= 0` (pair_rank_loss_layer.cu:51).  They differ only where margin - y*(a-b) is exactly 0.
 // Per calling thread (a Caffe host runs one thread per GPU); default: the CPU code's strict `>`.
-constexpr int kTicketSlots = 256;
 constexpr int kTicketTop = 1024;      // words 0..1023 of a ticket slot: one per group of kTicketGroup workgroups; then the top word
 constexpr int kTicketStride = kTicketTop + 32;
 constexpr int kTicketGroup = 16;
@@ -787,6 +787,7 @@ __global__ __launch_bounds__(THREADS) void triplet_generic_kernel(
 
   const int row0 = blockIdx.x * ROWS;
   const int rows = min(ROWS, N - row0);
+  if (rows <= 0) return;                             // uniform per workgroup: no barrier is skipped by part of one
   const size_t base = (size_t)row0 * D;
   const int total = rows * D;
   for (int i = threadIdx.x; i < total; i += THREADS) {
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(THREADS) void triplet_generic_kernel(
     terms[r] = t;
   }
   __syncthreads();
-  if (threadIdx.x < rows) partials[row0 + threadIdx.x] = terms[threadIdx.x];   // one term per triplet, like the wave kernels
+  if ((int)threadIdx.x < rows) partials[row0 + threadIdx.x] = terms[threadIdx.x];   // one term per triplet, like the wave kernels
   for (int i = threadIdx.x; i < total; i += THREADS) {
     const int r = i / D;
     const float tp = euclid_tt_exact(cs[0][r], dens[0][r], dpos[i]);
@@ -837,28 +838,20 @@ __global__ __launch_bounds__(THREADS) void triplet_generic_kernel(
 constexpr int kTripRows = 8;
 constexpr int kTripThreads = 256;
 
-// Arrival tickets of the in-launch loss reduction.  A slot is zero when no launch is using it (module load
-// zeroes them; the launch's last workgroup resets its slot), and consecutive calls take consecutive slots, so
-// launches in flight together -- other streams, other captured graphs -- never share one (a slot comes round
-// again after kTicketSlots calls).
-__device__ unsigned long long g_triplet_tickets[kTicketSlots * kTicketStride];
-static unsigned long long* next_ticket_slot() {
-  static std::atomic<unsigned> next{0};
-  static thread_local unsigned long long* base = nullptr;    // device address of the array on this thread's current device
-  static thread_local int base_dev = -1;
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  if (base == nullptr || dev != base_dev) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_triplet_tickets)) != hipSuccess) return nullptr;
-    base = static_cast<unsigned long long*>(p);
-    base_dev = dev;
-  }
-  return base + (size_t)(next.fetch_add(1, std::memory_order_relaxed) % kTicketSlots) * kTicketStride;
-}
+// Arrival words of the in-launch loss reduction live at the HEAD of the caller's triplet workspace (kTicketStride
+// 64-bit words, then one float per triplet).  They are zero whenever no launch is using the workspace:
+// mms_triplet_workspace_init zeroes them once (and again after a launch that died mid-way), and the wave that
+// completes a word resets it.  A launch -- eager or as a node of a captured graph -- therefore owns the words of the
+// workspace it was given: the ABI's "one workspace per call in flight" rule covers them, and nothing about them is
+// chosen at call time by host state.
+constexpr size_t kTicketBytes = (size_t)kTicketStride * sizeof(unsigned long long);
 
-// one float per triplet
-size_t triplet_workspace_bytes(int N) { return (size_t)N * sizeof(float); }
+size_t triplet_workspace_bytes(int N) { return kTicketBytes + (size_t)N * sizeof(float); }
+
+int triplet_workspace_init(void* ws, size_t ws_bytes, hipStream_t s) {
+  if (ws == nullptr || ws_bytes < kTicketBytes || (reinterpret_cast<uintptr_t>(ws) & 7u)) return MMS_ERR_WORKSPACE;
+  return hipMemsetAsync(ws, 0, kTicketBytes, s) == hipSuccess ? MMS_OK : MMS_ERR_LAUNCH;
+}
 
 int triplet_euclid_step(int N, int D, float margin, float loss_weight, const float* q,
                         const float* ap, const float* an, const float* y, float* s_pos,
@@ -868,7 +861,9 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
   if (ws == nullptr || ws_bytes < triplet_workspace_bytes(N)) return MMS_ERR_WORKSPACE;
   const float scale = loss_weight / (float)N;  // pair_rank_loss_layer.cpp:64, count = N*1
   const float s0 = -1.0f * scale, s1 = 1.0f * scale;
-  float* partials = static_cast<float*>(ws);
+  if (reinterpret_cast<uintptr_t>(ws) & 7u) return MMS_ERR_WORKSPACE;
+  unsigned long long* const tickets = static_cast<unsigned long long*>(ws);
+  float* partials = reinterpret_cast<float*>(static_cast<char*>(ws) + kTicketBytes);
   const int hge = pairrank_hinge_mode() == MMS_PAIRRANK_HINGE_GPU ? 1 : 0;
   const bool v = (D % 4 == 0) && aligned16(q) && aligned16(ap) && aligned16(an) &&
                  aligned16(dq) && aligned16(dap) && aligned16(dan);
@@ -902,7 +897,7 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
     const unsigned ngrp = (grid + kTicketGroup - 1) / kTicketGroup;
     unsigned long long* tk = (triplet_finish_mode() != MMS_TRIPLET_FINISH_INLAUNCH || ngrp > (unsigned)kTicketTop ||
                               loss_sum_mode() == MMS_LOSS_SUM_REFERENCE || loss == nullptr)
-                                 ? nullptr : next_ticket_slot();
+                                 ? nullptr : tickets;
     int lg = 0;
     while (((long long)1 << lg) < (long long)N) ++lg;
     const double fx_scale = std::ldexp(1.0, kFxSumBits - kFxTermBits - lg);
@@ -931,8 +926,8 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
   } else {
     const size_t lds = 2 * (size_t)kTripRows * D * sizeof(float);
     if (lds > 96 * 1024) return MMS_ERR_UNSUPPORTED;
-    nparts = N;
-    hipLaunchKernelGGL((triplet_generic_kernel<kTripRows, kTripThreads>), dim3(nparts),
+    nparts = N;                                    // one term per triplet; a workgroup owns kTripRows triplets
+    hipLaunchKernelGGL((triplet_generic_kernel<kTripRows, kTripThreads>), dim3((unsigned)((N + kTripRows - 1) / kTripRows)),
                        dim3(kTripThreads), lds, s, N, D, margin, s0, s1, q, ap, an, y, s_pos,
                        s_neg, partials, dq, dap, dan, hge);
   }

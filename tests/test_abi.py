@@ -25,7 +25,7 @@ def test_header_symbols_exported(hiplib):
 
 
 def test_version_and_error_strings(hiplib):
-    assert hiplib.mms_version() == 100
+    assert hiplib.mms_version() == 200          # include/mms.h MMS_VERSION: bumped with every incompatible change
     assert hiplib.mms_error_string(0) == b"ok"
     assert b"workspace" in hiplib.mms_error_string(3)
 
@@ -37,7 +37,8 @@ def test_workspace_queries_are_host_only(hiplib):
     assert need >= 2 * 16384 * 300 * 4
     assert hiplib.mms_simcross_workspace_bytes(7, 1, 1, 1, 1, 1) == 0       # bad mode
     assert hiplib.mms_pairrank_workspace_bytes(4096) in (0, 16)
-    assert hiplib.mms_triplet_workspace_bytes(4096) == 4096 * 4
+    assert hiplib.mms_triplet_workspace_bytes(4096) == 1056 * 8 + 4096 * 4   # arrival words, then one term per triplet
+    assert hiplib.mms_triplet_workspace_init(None, 0, None) == 3             # MMS_ERR_WORKSPACE, nothing enqueued
     assert hiplib.mms_simmatrix_workspace_bytes(16384, 300, 300) > 16384 * 300 * 4
 
 

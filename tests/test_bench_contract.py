@@ -46,3 +46,68 @@ def test_bench_refuses_without_gpu_or_falls_loudly():
                          capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode != 0
     assert "no CPU fallback" in (out.stderr + out.stdout)
+
+
+def test_bench_gpus_n_as_typed_starts_its_own_ranks_and_relays_failure():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts the rank processes itself
+    (tools/caffe.cpp:154-227 starts its per-GPU workers from one command too).  Without a GPU every rank refuses
+    loudly and the parent exits with a rank's return code instead of asking for torch.distributed.run."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_bench_two_ranks_as_typed")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--steps", "4", "--warmup", "1", "--no-variants"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    assert out.stderr.count("no CPU fallback") == 2, out.stderr[-2000:]      # one refusal per rank
+    assert "torch.distributed.run" not in out.stderr
+    assert out.stdout.strip() == ""
+
+
+def test_launch_ranks_sets_the_rendezvous_environment(tmp_path):
+    """The launcher's contract, without a GPU: N children, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rank 0's stdout
+    relayed, worst return code returned."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    probe = tmp_path / "probe.py"
+    probe.write_text("import os, sys\n"
+                     "r = int(os.environ['RANK'])\n"
+                     "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                     "assert os.environ['LOCAL_RANK'] == os.environ['RANK'] and os.environ['WORLD_SIZE'] == '3'\n"
+                     "print('rank', r, sys.argv[1:])\n"
+                     "sys.exit(7 if r == 2 else 0)\n")
+    real = bench.__file__
+    bench.__file__ = str(probe)
+    try:
+        import io
+        import contextlib
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            args = type("A", (), {"gpus": 3})()
+            rc = bench.launch_ranks(args, ["--gpus", "3", "--steps", "4"])
+    finally:
+        bench.__file__ = real
+    assert rc == 7
+    assert buf.getvalue().strip() == "rank 0 ['--gpus', '3', '--steps', '4']"
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_as_typed():
+    """`python bench.py --gpus 2 --backend gloo ...` as typed on ONE GPU: two rank processes share the card
+    (rehearsal of the N > 1 control flow), one JSON line comes back through the parent."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["scaling"] == "weak"
+    assert d["steps"] == 4 and d["warmup"] == 1
+    assert abs(d["value"] - 2 * 4096 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    sv = d["config"]["strong_split_variant"]
+    assert sv["scaling"] == "strong" and sv["pairs_per_gpu"] == 2048 and sv["value"] > 0

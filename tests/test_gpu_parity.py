@@ -628,7 +628,7 @@ def test_triplet_step_many_launches_and_graph_replay(hiplib):
     y = (torch.rand(N, 1, device="cuda", generator=g) < 0.8).float()
     mk = lambda: dict(s_pos=nan_like((N, 1)), s_neg=nan_like((N, 1)), loss=nan_like((1,)),
                       dq=nan_like(q.shape), da_pos=nan_like(q.shape), da_neg=nan_like(q.shape))
-    ws = capi.Workspace()
+    ws = capi.TripletWorkspace()
     two = mk()
     capi.set_triplet_finish_mode("launch")
     try:
@@ -774,6 +774,129 @@ def test_triplet_step(cfg, finish, oracle, hiplib):
     assert_bitexact(host(out["dq"]), dq_ref, "dq")
     assert_bitexact(host(out["da_pos"]), dap_ref, "da_pos")
     assert_bitexact(host(out["da_neg"]), dan_ref, "da_neg")
+
+
+@pytest.mark.parametrize("cfg", [(13, 50), (77, 301), (9, 1100), (1, 7), (8, 50), (4096, 300), (19, 1024)])
+def test_triplet_step_stays_inside_its_buffers(cfg, oracle, hiplib):
+    """Every output and the workspace are allocated at EXACTLY the size the ABI asks for, inside one arena with
+    canary words between and after them: the step (all three kernel families: D = 100/200/300, D % 4 == 0, and
+    the generic one-workgroup-per-8-triplets kernel for any other width) must leave every canary untouched and
+    give the oracle's bits."""
+    import ctypes as C
+    from mms_answer_selection_amd import capi
+    N, D = cfg
+    r = rng(N * 31 + D)
+    q, ap = qa(r, N, 1, 1, D)
+    _, an = qa(r, N, 1, 1, D)
+    y = (r.uniform(size=(N, 1)) < 0.8).astype(np.float32)
+    sp, _, _ = oracle.simcross_forward(1, q, ap)
+    sn, _, _ = oracle.simcross_forward(1, q, an)
+    loss_ref, o, sres = oracle.pairrank_forward(sp.reshape(N, 1), sn.reshape(N, 1), y, 0.05)
+    gsp, gsn = oracle.pairrank_backward(y, o, sres, top_diff=1.0)
+    dq_p, dap_ref, _, _ = oracle.simcross_backward(1, q, ap, sp, gsp.reshape(sp.shape))
+    dq_n, dan_ref, _, _ = oracle.simcross_backward(1, q, an, sn, gsn.reshape(sn.shape))
+    wsb = hiplib.mms_triplet_workspace_bytes(N)
+    assert wsb % 4 == 0
+    sizes = dict(ws=wsb // 4, s_pos=N, s_neg=N, loss=1, dq=N * D, da_pos=N * D, da_neg=N * D)
+    CAN = 64                                                   # canary floats after every buffer (256 B keeps 16-B alignment)
+    total = sum(((n + 3) // 4 * 4) + CAN for n in sizes.values())
+    arena = torch.full((total,), -777.25, dtype=torch.float32, device="cuda")
+    off, view = 0, {}
+    for k, n in sizes.items():
+        view[k] = arena[off:off + n]
+        off += (n + 3) // 4 * 4 + CAN
+    lib = capi.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    capi.check(lib.mms_triplet_workspace_init(view["ws"].data_ptr(), wsb, st), "init")
+    dq_, dqa, dqn, dy = dev(q), dev(ap), dev(an), dev(y)
+    for finish in ("inlaunch", "launch"):
+        capi.set_triplet_finish_mode(finish)
+        try:
+            capi.check(lib.mms_triplet_euclid_step_f32(
+                N, D, 0.05, 1.0, dq_.data_ptr(), dqa.data_ptr(), dqn.data_ptr(), dy.data_ptr(),
+                view["s_pos"].data_ptr(), view["s_neg"].data_ptr(), view["loss"].data_ptr(), view["dq"].data_ptr(),
+                view["da_pos"].data_ptr(), view["da_neg"].data_ptr(), view["ws"].data_ptr(), wsb, st), "step")
+        finally:
+            capi.set_triplet_finish_mode("inlaunch")
+        torch.cuda.synchronize()
+        h = arena.cpu().numpy()
+        mask = np.ones(total, bool)
+        off = 0
+        for k, n in sizes.items():
+            mask[off:off + n] = False
+            off += (n + 3) // 4 * 4 + CAN
+        assert (h[mask] == np.float32(-777.25)).all(), "a canary word was overwritten (%s, finish=%s)" % (cfg, finish)
+        assert_bitexact(host(view["s_pos"]), sp.ravel(), "s_pos")
+        assert_bitexact(host(view["s_neg"]), sn.ravel(), "s_neg")
+        assert_bitexact(host(view["dq"]).reshape(q.shape), dq_p + dq_n, "dq")
+        assert_bitexact(host(view["da_pos"]).reshape(q.shape), dap_ref, "da_pos")
+        assert_bitexact(host(view["da_neg"]).reshape(q.shape), dan_ref, "da_neg")
+        assert_close(host(view["loss"])[0], loss_ref, TOL, "loss")
+        # the arrival words are zero again after the launch
+        words = view["ws"][:1056 * 2].view(torch.int32)
+        assert int(words.abs().max().item()) == 0, "arrival words not reset"
+
+
+def test_triplet_workspaces_are_independent_and_recoverable(hiplib):
+    """Two graphs of 300 steps each, captured on their own workspaces and replayed CONCURRENTLY on two streams,
+    return the single launch's loss (round 2 drew arrival slots from a process-wide table at capture time: such
+    graphs shared slots).  A workspace whose arrival words were left non-zero (what a launch that died mid-way
+    leaves) gives NaN-or-stale, never silently affects ANOTHER workspace, and is whole again after reset()."""
+    from mms_answer_selection_amd import capi
+    N, D = 4096, 300
+    g = torch.Generator(device="cuda").manual_seed(11)
+    mkin = lambda: (torch.randn(N, 1, D, device="cuda", generator=g) * 0.4,
+                    torch.randn(N, 1, D, device="cuda", generator=g) * 0.4,
+                    torch.randn(N, 1, D, device="cuda", generator=g) * 0.4,
+                    (torch.rand(N, 1, device="cuda", generator=g) < 0.8).float())
+    mk = lambda: dict(s_pos=nan_like((N, 1)), s_neg=nan_like((N, 1)), loss=nan_like((1,)),
+                      dq=nan_like((N, 1, D)), da_pos=nan_like((N, 1, D)), da_neg=nan_like((N, 1, D)))
+    ins = [mkin(), mkin()]
+    refs = []
+    for x in ins:
+        o = mk()
+        capi.triplet_euclid_step(*x, margin=0.05, **o)
+        torch.cuda.synchronize()
+        refs.append(host(o["loss"]).copy())
+    assert np.isfinite(refs[0]).all() and np.isfinite(refs[1]).all() and refs[0][0] != refs[1][0]
+    wss = [capi.TripletWorkspace(), capi.TripletWorkspace()]
+    outs = [mk(), mk()]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    graphs = []
+    for i in range(2):
+        streams[i].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(streams[i]):
+            capi.triplet_euclid_step(*ins[i], margin=0.05, ws=wss[i], **outs[i])     # allocates + initialises
+            gph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gph, stream=streams[i]):
+                for _ in range(300):
+                    capi.triplet_euclid_step(*ins[i], margin=0.05, ws=wss[i], **outs[i])
+            graphs.append(gph)
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for i in range(2):
+            outs[i]["loss"].fill_(float("nan"))
+        torch.cuda.synchronize()
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                graphs[i].replay()
+        torch.cuda.synchronize()
+        for i in range(2):
+            assert_bitexact(host(outs[i]["loss"]), refs[i], "concurrent graph %d, replay %d" % (i, rep))
+    # poison workspace 0's arrival words; workspace 1 is unaffected; reset() repairs workspace 0
+    wss[0].buf[:1056 * 8].view(torch.int64).fill_((5 << 52) | (1 << 40))   # stray arrivals and a stray partial sum
+    o0, o1 = mk(), mk()
+    capi.triplet_euclid_step(*ins[0], margin=0.05, ws=wss[0], **o0)
+    capi.triplet_euclid_step(*ins[1], margin=0.05, ws=wss[1], **o1)
+    torch.cuda.synchronize()
+    assert_bitexact(host(o1["loss"]), refs[1], "a poisoned workspace must not leak into another one")
+    l0 = host(o0["loss"])[0]
+    assert np.isnan(l0) or l0 != refs[0][0]                    # garbage in, no promise -- but only for ITS owner
+    wss[0].reset()
+    o0 = mk()
+    capi.triplet_euclid_step(*ins[0], margin=0.05, ws=wss[0], **o0)
+    torch.cuda.synchronize()
+    assert_bitexact(host(o0["loss"]), refs[0], "after mms_triplet_workspace_init the workspace is whole again")
 
 
 # --------------------------------------------------------------------------- #

@@ -12,7 +12,7 @@ q, ap, an = mk(ring, N, 1, D), mk(ring, N, 1, D), mk(ring, N, 1, D)
 y = (torch.rand(ring, N, 1, device="cuda", generator=g) < 0.8).float()
 dq, dp, dn = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
 sp, sn, loss = torch.empty(ring, N, 1, device="cuda"), torch.empty(ring, N, 1, device="cuda"), torch.empty(ring, 1, device="cuda")
-ws = capi.Workspace()
+ws = capi.TripletWorkspace()
 step = lambda i: capi.triplet_euclid_step(q[i], ap[i], an[i], y[i], sp[i], sn[i], loss[i], dq[i], dp[i], dn[i], margin=0.05, ws=ws)
 for i in range(ring): step(i)
 torch.cuda.synchronize()
