@@ -1230,4 +1230,10 @@ if __name__ == "__main__":
     _args = parse()
     if _args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(_args, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # native libraries chat on fd 1 ("[Gloo] Rank 0 is connected to ..."): the contract is ONE JSON line on
+        # stdout, so fd 1 is pointed at stderr for the rest of the process and print() keeps the real stdout
+        _real = os.dup(1)
+        os.dup2(2, 1)
+        sys.stdout = os.fdopen(_real, "w")
     run(_args)
