@@ -176,10 +176,44 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       akk[jj] = kk;
     }
   }
+  // Round 3 (tools/mfmastruct.hip, profiles/r03_mfmastruct.txt): a VALU instruction issued by a loader wave costs the
+  // compute wave on its SIMD ~8.5 cycles of matrix-pipe time, and the per-slot address arithmetic below (selects and
+  // 64-bit adds: ~6 VALU instructions per DMA, 84 per tile) is what held the main loop at ~40 cycles per MFMA instead
+  // of the 33 the same DMAs cost when issued without any: 19 MFMAs + 19 operand reads per k-step run at 32.1 cycles
+  // per MFMA alone, 33.3 beside 14 DMAs per tile, 36.8 beside 84 VALU instructions, 41.6 beside both.  A FULL tile
+  // therefore issues with none: the tile's origin is a scalar base (SALU), the per-lane byte offsets are
+  // tile-invariant registers (slots that hold nothing fetch the tile's first bytes), M0 moves are SALU.  Only a
+  // partial tile (the last of a segment) takes the selects.
+  unsigned bvo[NBW], avo[NAW];
+#pragma unroll
+  for (int jj = 0; jj < NBW; ++jj) bvo[jj] = boff[jj] >= 0 ? (unsigned)boff[jj] * 4u : 0u;
+#pragma unroll
+  for (int jj = 0; jj < NAW; ++jj) avo[jj] = aoff[jj] >= 0 ? (unsigned)aoff[jj] * 4u : 0u;
+  const unsigned svo = (unsigned)(lane & 31) * 4u;
+  auto dma16s = [&](const float* sbase, unsigned voff, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+  };
+  auto dma4s = [&](const float* sbase, unsigned voff, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+  };
   auto issue_tile = [&](int stage, int seg, int k0) {
+    seg = __builtin_amdgcn_readfirstlane(seg);          // wave-uniform by construction; said so, the tile origins below
+    k0 = __builtin_amdgcn_readfirstlane(k0);            // are scalar registers (the DMAs take them as their SGPR base)
     const unsigned sb = lds_base + (unsigned)(stage * STAGE_F) * 4u;
     const float* Bs = Bb + (long long)seg * p.b_seg + (long long)k0 * p.ldb;
     const float* As = p.A + (long long)seg * p.a_seg + (A_KC ? (long long)k0 : (long long)k0 * p.lda);
+    if (k0 + 32 <= kend) {                              // a full tile (wave-uniform)
+#pragma unroll
+      for (int jj = 0; jj < NBW; ++jj) dma16s(Bs, bvo[jj], sb + (unsigned)(wave + 4 * jj) * 1024u);
+#pragma unroll
+      for (int jj = 0; jj < NAW; ++jj) dma16s(As, avo[jj], sb + (unsigned)G::B_F * 4u + (unsigned)(wave + 4 * jj) * 1024u);
+      if (!A_KC) dma4s(p.kscale + k0, svo, sb + (unsigned)(G::B_F + G::A_F) * 4u);
+      return;
+    }
 #pragma unroll
     for (int jj = 0; jj < NBW; ++jj) {
       const bool ok = boff[jj] >= 0 && k0 + bkk[jj] < kend;
@@ -580,7 +614,7 @@ inline bool panel_eligible(const PanelArgs& p, bool a_kc) {
   if (p.side_in && (p.ksplit != 1 || p.nb != 1 || !pg_mult4(p.side_cols) || p.side_cols > 16 * nt || !pg_mult4(p.side_ld) ||
                     !aligned16(p.side_in) || !aligned16(p.side_out) || !p.side_scale))
     return false;
-  if ((long long)p.M * p.lda >= (1LL << 31) || 64LL * p.ldb >= (1LL << 31)) return false;   // 32-bit slot offsets
+  if ((long long)p.M * p.lda >= (1LL << 30) || 64LL * p.ldb >= (1LL << 30)) return false;   // 32-bit slot BYTE offsets
   // a panel kernel launch has row_blocks x ksplit x nb workgroups of 4 waves: below ~a third of the chip the
   // 64 x 64 tiling's extra parallelism wins
   return (long long)p.row_blocks * p.ksplit * p.nb >= 96;
