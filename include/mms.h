@@ -95,6 +95,12 @@ int mms_null_launch(int workgroups, void* stream);
  * Forward uses it for loss tops in GPU mode where the reference calls caffe_gpu_dot
  * (include/caffe/layer.hpp:469-481, src/caffe/util/math_functions.cu caffe_gpu_dot). */
 int mms_dot_f32(int n, const float* x, const float* y, float* out, void* stream);
+
+/* SplitLayer::Backward (src/caffe/layers/split_layer.cpp:38-57, split_layer.cu:19-34): the gradient of a blob that
+ * feeds `ntop` consumers is the sum of their gradients, formed in consumer order: bottom = top_0 (ntop == 1: a copy),
+ * (top_0 + top_1), then + top_2, ... -- the reference's caffe_gpu_add followed by caffe_gpu_axpy(1, ...), same
+ * association, hence the same bits.  `top_diffs`: a HOST array of ntop DEVICE pointers; bottom_diff may be top_diffs[0]. */
+int mms_split_backward_f32(int count, int ntop, const float* const* top_diffs, float* bottom_diff, void* stream);
 int mms_dot_f64(int n, const double* x, const double* y, double* out, void* stream);
 
 #define MMS_PAIRRANK_HINGE_CPU 0

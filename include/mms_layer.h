@@ -83,6 +83,10 @@ void mms_net_destroy(mms_net_t* n);
  * SimCross layers the current plan runs that way (after mms_net_setup). */
 int mms_net_set_option(mms_net_t* n, const char* key, int value);
 int mms_net_num_fused(const mms_net_t* n);
+/* Blobs that feed more than one back-propagating layer get Net::Init's Split treatment (insert_splits.cpp:13-88): each
+ * consumer reads the blob through a blob of its own (data shared, diff private) and mms_net_backward sums the diffs in
+ * consumer order (split_layer.cpp:38-57) before the producer's Backward.  mms_net_num_splits: how many blobs. */
+int mms_net_num_splits(const mms_net_t* n);
 const char* mms_net_name(const mms_net_t* n);
 int mms_net_num_layers(const mms_net_t* n);
 const char* mms_net_layer_name(const mms_net_t* n, int i);

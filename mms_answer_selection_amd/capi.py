@@ -56,6 +56,7 @@ _SIGNATURES = {
     "mms_simcross_forward_block_f32": (_i, [_vp, _vp]),
     "mms_simcross_backward_block_f32": (_i, [_vp, _vp]),
     "mms_dot_f32": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "mms_split_backward_f32": (_i, [_i, _i, _vp, _vp, _vp]),
     "mms_dot_f64": (_i, [_i, _vp, _vp, _vp, _vp]),
     "mms_set_f16_distance_mode": (_i, [_i]),
     "mms_get_f16_distance_mode": (_i, []),

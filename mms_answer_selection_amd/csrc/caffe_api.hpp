@@ -211,6 +211,9 @@ class Blob {
   Dtype* mutable_gpu_diff() { CHECK(diff_); return (Dtype*)diff_->mutable_gpu_data(); }
   const shared_ptr<SyncedMemory>& data() const { return data_; }
   const shared_ptr<SyncedMemory>& diff() const { return diff_; }
+  // blob.cpp:148-158: this blob's data (diff) becomes the other's -- what SplitLayer::Reshape does to its tops
+  void ShareData(const Blob& other) { CHECK_EQ(count_, other.count()); data_ = other.data(); }
+  void ShareDiff(const Blob& other) { CHECK_EQ(count_, other.count()); diff_ = other.diff(); }
 
  private:
   shared_ptr<SyncedMemory> data_, diff_;

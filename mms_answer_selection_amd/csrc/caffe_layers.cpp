@@ -1307,6 +1307,7 @@ class PathNet {
       L.runnable = true;
       ++n;
     }
+    insert_splits();
     plan_fusion();
     return n;
   }
@@ -1325,6 +1326,9 @@ class PathNet {
     for (size_t i = 0; i < layers_.size(); ++i) {
       PathNetLayer& L = layers_[i];
       if (!L.runnable || skipped_.count(i)) continue;
+      for (Split& sp : splits_)                                    // SplitLayer::Reshape: the tops share the bottom's data
+        for (size_t c = 0; c < sp.consumers.size(); ++c)
+          if (sp.consumers[c].first == i) { sp.alias[c]->ReshapeLike(*sp.orig); sp.alias[c]->ShareData(*sp.orig); }
       auto f = fused_.find(i);
       if (f != fused_.end()) {
         PathNetLayer& Eq = layers_[f->second.first];
@@ -1347,18 +1351,16 @@ class PathNet {
                           "Embed tops were never written";
     for (size_t i = layers_.size(); i-- > 0;) {
       PathNetLayer& L = layers_[i];
+      for (Split& sp : splits_) if (sp.producer == (int)i) split_backward(sp);     // every consumer has run by now
       if (!L.runnable) continue;
-      const string t = L.param.type();
-      if (t == "HDF5Data" || t == "MAP" || t == "MRR" || t == "AUC" || t == "RankAccuracy") continue;   // no backward
+      if (!has_backward(L)) continue;
       vector<bool> pd(L.bottom.size(), true);
-      for (size_t b = 0; b < L.bottom.size(); ++b) {
-        if (t == "Embed") pd[b] = false;                             // indices (embed_layer.cpp:156)
-        if (t == "PairRankLoss" && b == 2) pd[b] = false;            // labels (pair_rank_loss_layer.cpp:58-61)
-        if (produced_by_data_.count(L.bottom_names[b])) pd[b] = false;
-      }
+      for (size_t b = 0; b < L.bottom.size(); ++b) pd[b] = propagates(L, b);
       L.layer->Backward(L.top, pd, L.bottom);
     }
+    for (Split& sp : splits_) if (sp.producer < 0) split_backward(sp);             // net inputs
   }
+  int num_splits() const { return (int)splits_.size(); }
   Blob<float>* find_blob(const string& n) { auto it = blobs_.find(n); return it == blobs_.end() ? nullptr : it->second; }
   vector<PathNetLayer>& layers() { return layers_; }
   const vector<string>& blob_names() const { return blob_order_; }
@@ -1396,6 +1398,66 @@ class PathNet {
       CHECK_EQ(it->second->count(), blobs[i]->count()) << "Shared parameter '" << pn << "' has mismatched sizes";
       blobs[i] = it->second;                                         // ShareData + ShareDiff with the owner
     }
+  }
+  static bool has_backward(const PathNetLayer& L) {
+    const string t = L.param.type();
+    return !(t == "HDF5Data" || t == "MAP" || t == "MRR" || t == "AUC" || t == "RankAccuracy");
+  }
+  bool propagates(const PathNetLayer& L, size_t b) const {
+    const string t = L.param.type();
+    if (t == "Embed") return false;                                // indices (embed_layer.cpp:156)
+    if (t == "PairRankLoss" && b == 2) return false;               // labels (pair_rank_loss_layer.cpp:58-61)
+    if (produced_by_data_.count(L.bottom_names[b])) return false;
+    return true;
+  }
+  // What Net::Init's InsertSplits does (src/caffe/util/insert_splits.cpp:13-88, net.cpp:57): a blob that feeds more
+  // than one layer gets a Split layer, whose tops share its data and own their diffs, and whose Backward SUMS those
+  // diffs into the blob's (split_layer.cpp:38-57).  Without it each consumer's Backward overwrites the blob's diff
+  // and the last one wins.  Here: every consumer that propagates down into such a blob reads it through a blob of
+  // its own (data shared, diff private) and the sum is taken -- in consumer order, like the reference -- right
+  // before the producing layer's Backward.  This also gives SimMatrix's bottom[1] a diff no sibling touches: its
+  // Forward parks Q.W there (sim_matrix_layer.cpp:58).
+  struct Split {
+    Blob<float>* orig;
+    int producer;                                                  // layer index, -1: a net input
+    vector<std::pair<size_t, size_t> > consumers;                  // (layer, bottom index), file order
+    vector<Blob<float>*> alias;
+  };
+  void insert_splits() {
+    if (!splits_.empty()) return;                                  // SetUp may run again; the wiring is done once
+    for (const string& name : blob_order_) {
+      Blob<float>* b = blobs_[name];
+      Split sp;
+      sp.orig = b;
+      sp.producer = -1;
+      bool in_place = false;
+      for (size_t i = 0; i < layers_.size(); ++i) {
+        const PathNetLayer& L = layers_[i];
+        for (size_t k = 0; k < L.top.size(); ++k) if (L.top[k] == b) sp.producer = (int)i;
+        if (!L.runnable || !has_backward(L)) continue;
+        for (size_t k = 0; k < L.bottom.size(); ++k) {
+          if (L.bottom[k] != b || !propagates(L, k)) continue;
+          sp.consumers.emplace_back(i, k);
+          for (Blob<float>* t : L.top) if (t == b) in_place = true;
+        }
+      }
+      if (sp.consumers.size() < 2 || in_place || b->count() == 0) continue;
+      for (auto& c : sp.consumers) {
+        owned_.emplace_back(new Blob<float>());
+        Blob<float>* a = owned_.back().get();
+        a->ReshapeLike(*b);
+        a->ShareData(*b);
+        sp.alias.push_back(a);
+        layers_[c.first].bottom[c.second] = a;
+      }
+      splits_.push_back(sp);
+    }
+  }
+  void split_backward(Split& sp) {
+    vector<const float*> tops;
+    for (Blob<float>* a : sp.alias) tops.push_back(a->gpu_diff());
+    mms_check(mms_split_backward_f32(sp.orig->count(), (int)tops.size(), tops.data(), sp.orig->mutable_gpu_diff(), nullptr),
+              "mms_split_backward_f32");
   }
   void plan_fusion() {
     fused_.clear();
@@ -1439,6 +1501,7 @@ class PathNet {
   vector<std::unique_ptr<Blob<float> > > owned_;
   std::map<string, shared_ptr<Blob<float> > > shared_params_;
   std::set<string> produced_by_data_;
+  vector<Split> splits_;
 };
 }  // namespace caffe
 
@@ -1540,6 +1603,7 @@ mms_net_t* mms_net_create(const char* prototxt, int phase, char* err, int err_le
 void mms_net_destroy(mms_net_t* n) { delete n; }
 int mms_net_set_option(mms_net_t* n, const char* key, int value) { return (key && n->net->SetOption(key, value)) ? 0 : 1; }
 int mms_net_num_fused(const mms_net_t* n) { return n->net->num_fused(); }
+int mms_net_num_splits(const mms_net_t* n) { return n->net->num_splits(); }
 const char* mms_net_name(const mms_net_t* n) { return n->net->name().c_str(); }
 int mms_net_num_layers(const mms_net_t* n) { return (int)n->net->layers().size(); }
 const char* mms_net_layer_name(const mms_net_t* n, int i) { return n->net->layers()[i].param.name().c_str(); }

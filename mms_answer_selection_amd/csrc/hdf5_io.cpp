@@ -490,7 +490,7 @@ Emitted emit_dataset(Out& o, const WriteDataset& d) {
 }
 
 // members first (their addresses are needed by the symbol node), then this group's object header (one
-// symbol-table message), local heap, one-leaf B-tree and symbol node (at most 8 members: K = 4)
+// symbol-table message), local heap, one B-tree node and its symbol nodes (8 members each, up to 256 in all)
 bool emit_group(Out& o, const GroupNode& g, Emitted* out, std::string* err) {
   struct Member { std::string name; Emitted e; };
   std::vector<Member> mem;
@@ -501,7 +501,9 @@ bool emit_group(Out& o, const GroupNode& g, Emitted* out, std::string* err) {
     mem.push_back({kv.first, e});
   }
   std::sort(mem.begin(), mem.end(), [](const Member& a, const Member& b) { return a.name < b.name; });
-  if (mem.empty() || mem.size() > 8) return fail(err, "the HDF5 writer handles 1..8 members per group (one symbol node, K=4)");
+  // one B-tree node (internal K = 16: up to 32 children) over symbol nodes of up to 8 entries (leaf K = 4)
+  if (mem.empty() || mem.size() > 256) return fail(err, "the HDF5 writer handles 1..256 members per group (one B-tree node over 32 symbol nodes)");
+  const size_t nsnod = (mem.size() + 7) / 8;
   o.pad8();
   Emitted me{o.b.size(), 0, 0, true};
   o.u(1, 1); o.u(0, 1); o.u(1, 2); o.u(1, 4); o.u(24, 4); o.u(0, 4);
@@ -521,22 +523,30 @@ bool emit_group(Out& o, const GroupNode& g, Emitted* out, std::string* err) {
   o.b.insert(o.b.end(), heap.begin(), heap.end());
   me.btree = o.b.size();
   o.b.insert(o.b.end(), {'T', 'R', 'E', 'E'});
-  o.u(0, 1); o.u(0, 1); o.u(1, 2); o.u(kUndef, 8); o.u(kUndef, 8);
-  o.u(0, 8);
-  const size_t child_at = o.b.size(); o.u(0, 8);
-  o.u(name_off.back(), 8);
-  for (int i = 0; i < 2 * 16 - 1; ++i) { o.u(0, 8); o.u(0, 8); }   // unused key/child slots (2K = 32 entries)
+  o.u(0, 1); o.u(0, 1); o.u(nsnod, 2); o.u(kUndef, 8); o.u(kUndef, 8);
+  o.u(0, 8);                                                     // key 0: the empty string
+  std::vector<size_t> child_at;
+  for (size_t c = 0; c < nsnod; ++c) {                           // child c, then key c+1 = its LAST (largest) name
+    child_at.push_back(o.b.size()); o.u(0, 8);
+    const size_t last = std::min(mem.size(), 8 * (c + 1)) - 1;
+    o.u(name_off[last], 8);
+  }
+  for (size_t c = nsnod; c < 2 * 16; ++c) { o.u(0, 8); o.u(0, 8); }   // unused child/key slots (2K = 32 entries)
   o.patch(stm_at, me.btree, 8); o.patch(stm_at + 8, me.heap, 8);
-  o.patch(child_at, o.b.size(), 8);
-  o.b.insert(o.b.end(), {'S', 'N', 'O', 'D'});
-  o.u(1, 1); o.u(0, 1); o.u(mem.size(), 2);
-  for (size_t i = 0; i < 8; ++i) {
-    if (i < mem.size()) {
-      o.u(name_off[i], 8); o.u(mem[i].e.hdr, 8);
-      if (mem[i].e.group) { o.u(1, 4); o.u(0, 4); o.u(mem[i].e.btree, 8); o.u(mem[i].e.heap, 8); }
-      else { o.u(0, 4); o.u(0, 4); o.u(0, 8); o.u(0, 8); }
-    } else {
-      o.u(0, 8); o.u(0, 8); o.u(0, 4); o.u(0, 4); o.u(0, 8); o.u(0, 8);
+  for (size_t c = 0; c < nsnod; ++c) {
+    o.patch(child_at[c], o.b.size(), 8);
+    const size_t first = 8 * c, cnt = std::min<size_t>(8, mem.size() - first);
+    o.b.insert(o.b.end(), {'S', 'N', 'O', 'D'});
+    o.u(1, 1); o.u(0, 1); o.u(cnt, 2);
+    for (size_t i = 0; i < 8; ++i) {
+      if (i < cnt) {
+        const Member& m = mem[first + i];
+        o.u(name_off[first + i], 8); o.u(m.e.hdr, 8);
+        if (m.e.group) { o.u(1, 4); o.u(0, 4); o.u(m.e.btree, 8); o.u(m.e.heap, 8); }
+        else { o.u(0, 4); o.u(0, 4); o.u(0, 8); o.u(0, 8); }
+      } else {
+        o.u(0, 8); o.u(0, 8); o.u(0, 4); o.u(0, 4); o.u(0, 8); o.u(0, 8);
+      }
     }
   }
   *out = me;

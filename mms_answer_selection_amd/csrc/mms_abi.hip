@@ -136,6 +136,16 @@ __global__ __launch_bounds__(256) void dot_kernel(int n, const T* __restrict__ x
   }
   if (threadIdx.x == 0) *out = red[0];
 }
+struct SplitPtrs { const float* p[8]; };
+// out = ((carry? out : p0) + p1) + ... in index order
+__global__ __launch_bounds__(256) void split_sum_kernel(int n, int k, SplitPtrs s, int carry, float* __restrict__ out) {
+  const int stride = gridDim.x * 256;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float v = carry ? out[i] : s.p[0][i];
+    for (int j = carry ? 0 : 1; j < k; ++j) v = v + s.p[j][i];
+    out[i] = v;
+  }
+}
 }  // namespace mms
 
 extern "C" {
@@ -448,6 +458,20 @@ int mms_null_launch(int workgroups, void* stream) {
 int mms_dot_f32(int n, const float* x, const float* y, float* out, void* stream) {
   if (n < 0 || !out || (n > 0 && (!x || !y))) return MMS_ERR_INVALID_ARG;
   hipLaunchKernelGGL(mms::dot_kernel<float>, dim3(1), dim3(256), 0, as_stream(stream), n, x, y, out);
+  return launch_status();
+}
+int mms_split_backward_f32(int count, int ntop, const float* const* top_diffs, float* bottom_diff, void* stream) {
+  if (count < 0 || ntop < 1 || !top_diffs || (count > 0 && !bottom_diff)) return MMS_ERR_INVALID_ARG;
+  for (int i = 0; i < ntop; ++i) if (count > 0 && !top_diffs[i]) return MMS_ERR_INVALID_ARG;
+  if (count == 0) return MMS_OK;
+  const unsigned grid = (unsigned)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
+  for (int first = 0; first < ntop; first += 8) {
+    mms::SplitPtrs s{};
+    const int k = ntop - first < 8 ? ntop - first : 8;
+    for (int j = 0; j < k; ++j) s.p[j] = top_diffs[first + j];
+    hipLaunchKernelGGL(mms::split_sum_kernel, dim3(grid), dim3(256), 0, as_stream(stream), count, k, s, first > 0 ? 1 : 0,
+                       bottom_diff);
+  }
   return launch_status();
 }
 int mms_dot_f64(int n, const double* x, const double* y, double* out, void* stream) {

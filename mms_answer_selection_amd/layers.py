@@ -47,6 +47,7 @@ _SIGNATURES = {
     "mms_net_destroy": (None, [_vp]),
     "mms_net_set_option": (_i, [_vp, C.c_char_p, _i]),
     "mms_net_num_fused": (_i, [_vp]),
+    "mms_net_num_splits": (_i, [_vp]),
     "mms_net_name": (C.c_char_p, [_vp]),
     "mms_net_num_layers": (_i, [_vp]),
     "mms_net_layer_name": (C.c_char_p, [_vp, _i]),
@@ -323,6 +324,11 @@ class Net:
     @property
     def num_fused(self):
         return lib().mms_net_num_fused(self._h)
+
+    @property
+    def num_splits(self):
+        """Blobs that feed several back-propagating layers and therefore got Split semantics (insert_splits.cpp)."""
+        return lib().mms_net_num_splits(self._h)
 
     def Forward(self):
         return float(lib().mms_net_forward(self._h))

@@ -135,8 +135,16 @@ def test_writer_round_trip_driver_format(tmp_path):
         assert (f[k] == v.astype(np.float32)).all()          # H5LTread_dataset_float: double -> float
     L.write_h5(p, {"x": np.arange(6, dtype=np.float32).reshape(2, 3)})
     assert L.H5File(p).info("x") == ((2, 3), 1, 4)
-    with pytest.raises(IOError, match="1..8 members"):
-        L.write_h5(p, {"d%d" % i: np.zeros(2) for i in range(9)})
+    # more than one symbol node per group (8 members each under one B-tree node): 9, 64 and 200 members read back
+    for n_members in (9, 64, 200):
+        many = {"d%03d" % i: r.standard_normal((2, 3)).astype(np.float32) for i in range(n_members)}
+        L.write_h5(p, many)
+        g = L.H5File(p)
+        assert g.keys() == sorted(many)
+        for k, v in many.items():
+            assert (g[k] == v).all()
+    with pytest.raises(IOError, match="1..256 members"):
+        L.write_h5(p, {"d%d" % i: np.zeros(2) for i in range(257)})
 
 
 def _tops(n):

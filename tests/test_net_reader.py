@@ -164,3 +164,77 @@ def test_network_v4_path_layers_run_from_the_net_file(L, oracle, tmp_path):
     # the next Forward serves the file's second batch
     net.Forward()
     assert_bitexact(net.blob("question").data, question[B:].astype(np.float32))
+
+
+TRIPLET_NET = """
+name: "triplet"
+input: "q"   input_shape { dim: 33 dim: 1 dim: 300 }
+input: "ap"  input_shape { dim: 33 dim: 1 dim: 300 }
+input: "an"  input_shape { dim: 33 dim: 1 dim: 300 }
+input: "y"   input_shape { dim: 33 dim: 1 }
+layer { name: "sp" type: "SimCross" bottom: "q" bottom: "ap" top: "s_pos" sim_cross_param { dist_mode: 1 } }
+layer { name: "sn" type: "SimCross" bottom: "q" bottom: "an" top: "s_neg" sim_cross_param { dist_mode: 1 } }
+layer { name: "loss" type: "PairRankLoss" bottom: "s_pos" bottom: "s_neg" bottom: "y" top: "loss"
+        pair_rank_loss_param { margin: 0.05 } }
+"""
+
+
+@pytest.mark.gpu
+def test_blob_feeding_two_layers_gets_split_semantics(L, oracle):
+    """Net::Init inserts a Split layer wherever a blob feeds more than one layer (insert_splits.cpp:13-88): each
+    consumer back-propagates into a diff of its own and SplitLayer::Backward sums them (split_layer.cpp:38-57).
+    `q` feeds both SimCross layers of the triplet net: its gradient is dq(pos) + dq(neg), in that order -- not the
+    last writer's."""
+    N, D = 33, 300
+    r = rng(91)
+    q = (r.standard_normal((N, 1, D)) * 0.4).astype(np.float32)
+    ap = (q + 0.1 * r.standard_normal((N, 1, D))).astype(np.float32)
+    an = (r.standard_normal((N, 1, D)) * 0.4).astype(np.float32)
+    y = (r.uniform(size=(N, 1)) < 0.8).astype(np.float32)
+    L.set_mode_gpu()
+    net = L.Net(TRIPLET_NET, phase="TRAIN")
+    for name, v in (("q", q), ("ap", ap), ("an", an), ("y", y)):
+        net.blob(name).data[...] = v
+    assert net.SetUp() == 3
+    assert net.num_splits == 1
+    loss = net.Forward()
+    sp, _, _ = oracle.simcross_forward(1, q, ap)
+    sn, _, _ = oracle.simcross_forward(1, q, an)
+    loss_ref, o, s = oracle.pairrank_forward(sp.reshape(N, 1), sn.reshape(N, 1), y, 0.05)
+    assert_bitexact(net.blob("s_pos").data.ravel(), sp.ravel())
+    assert_close(loss, loss_ref, TOL, "loss")
+    net.Backward()
+    gsp, gsn = oracle.pairrank_backward(y, o, s, top_diff=1.0)
+    dq_p, dap_ref, _, _ = oracle.simcross_backward(1, q, ap, sp, gsp.reshape(sp.shape))
+    dq_n, dan_ref, _, _ = oracle.simcross_backward(1, q, an, sn, gsn.reshape(sn.shape))
+    assert np.abs(dq_n).max() > 0 and np.abs(dq_p).max() > 0
+    assert_bitexact(net.blob("q").diff, dq_p + dq_n, "dq = Split backward of the two branches")
+    assert_bitexact(net.blob("ap").diff, dap_ref, "da_pos")
+    assert_bitexact(net.blob("an").diff, dan_ref, "da_neg")
+    # a second iteration (Reshape + ShareData of the split tops every Forward) gives the same bits
+    net.Forward()
+    net.Backward()
+    assert_bitexact(net.blob("q").diff, dq_p + dq_n, "second iteration")
+
+
+@pytest.mark.gpu
+def test_split_backward_abi_orders_its_sum(L):
+    """mms_split_backward_f32: ((t0 + t1) + t2) + ..., any number of tops, in place on t0 allowed."""
+    import ctypes as C
+    import torch
+    from mms_answer_selection_amd import capi
+    r = rng(5)
+    for ntop in (1, 2, 3, 11):
+        tops = [(r.standard_normal(1000) * 10.0 ** r.integers(-3, 4)).astype(np.float32) for _ in range(ntop)]
+        want = tops[0].copy()
+        for t in tops[1:]:
+            want = want + t
+        dev = [torch.from_numpy(t).cuda() for t in tops]
+        out = torch.full((1000,), float("nan"), device="cuda")
+        arr = (C.c_void_p * ntop)(*[d.data_ptr() for d in dev])
+        capi.check(capi.lib().mms_split_backward_f32(1000, ntop, arr, out.data_ptr(), None), "split")
+        torch.cuda.synchronize()
+        assert_bitexact(out.cpu().numpy(), want, "ntop=%d" % ntop)
+    capi.check(capi.lib().mms_split_backward_f32(1000, ntop, arr, dev[0].data_ptr(), None), "split in place")
+    torch.cuda.synchronize()
+    assert_bitexact(dev[0].cpu().numpy(), want, "in place on top 0")

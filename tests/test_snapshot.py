@@ -172,6 +172,13 @@ def test_hdf5_snapshot_round_trip(tmp_path):
         assert t == "" and len(gb) == len(blobs)
         for g, w in zip(gb, blobs):
             assert g.shape == w.shape and (g.view(np.uint32) == w.view(np.uint32)).all()
+    # a net with more parameter layers than one symbol node holds (Net::ToHDF5 has no such limit)
+    deep = [("ip%02d" % i, "SimMatrix", [r.standard_normal((3, 5)).astype(np.float32)]) for i in range(21)]
+    L.save_snapshot(p, "deep", raw_layers=deep, hdf5=True)
+    got = {n: bl for n, _, bl in L.Snapshot(p).layers()}
+    assert sorted(got) == [n for n, _, _ in deep]
+    for name, _, blobs in deep:
+        assert (got[name][0].view(np.uint32) == blobs[0].view(np.uint32)).all()
     bad = tmp_path / "feed.h5"                                    # an HDF5 file that is not a snapshot
     L.write_h5(bad, {"question": np.zeros((2, 3))})
     with pytest.raises(IOError, match="no /data group"):
