@@ -82,6 +82,11 @@ def parse():
                         "itself through pre-bound C-ABI calls, the way a native Layer host does (a hipGraphLaunch "
                         "costs 6.5 us of device time, a third of a microsecond per step in the driver's 20-step "
                         "regions); auto = eager for the layers path when --steps < 1024, graph otherwise")
+    p.add_argument("--f16-distance", choices=["ordered", "tree"], default="ordered",
+                   help="--workload cfg5: 'ordered' = the reference's d-ascending fp32 sum of the 1024 squares, scores "
+                        "bit-identical to the fp32 CPU code on the fp16-rounded inputs; 'tree' = fixed-shape tree sum, "
+                        "within ~1e-6 relative of it -- SURVEY 8(d) asks 1e-3 of this configuration (the reference has "
+                        "no fp16), so both are contract-compliant; the line reports both accountings either way")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -763,6 +768,7 @@ def run_cfg5(args, torch, dist, capi, world, rank):
     per-pair scores are all-gathered after every step (256 KiB in all) on a side stream, double-buffered."""
     from mms_answer_selection_amd import sharded
     NT, D = 65536, 1024
+    capi.set_f16_distance_mode(args.f16_distance)
     lo, hi = sharded.shard_range(NT, rank, world)
     n = hi - lo
     ring = max(2, min(16, (1 << 30) // (n * D * 2 * 4)))      # ~1 GiB of distinct shards per rank
@@ -813,6 +819,7 @@ def run_cfg5(args, torch, dist, capi, world, rank):
     t_ms = median(ev_ms)
     if rank == 0:
         b_unfused = 2 * (3 * NT * 2 * D) + 4 * 3 * NT                 # SURVEY 8(d), s = 2, whole batch
+        b_moved = 2 * (2 * NT * 2 * D) + 4 * 2 * NT                   # the fused launch: q, a read once; dq, da written once
         step_us = t_ms * 1e3 / K
         out = {"metric": "QA pairs/sec (fwd+bwd), cfg 5: 65,536 x 1024 fp16 storage; % HBM roofline",
                "value": NT * K / (t_ms * 1e-3), "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -828,8 +835,17 @@ def run_cfg5(args, torch, dist, capi, world, rank):
                "roofline": {"bound": "hbm", "achieved": b_unfused / (step_us * 1e-6) / 1e9 / world,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": b_unfused / (step_us * 1e-6) / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
-                            "note": "per GPU: SURVEY 8(d) unfused bytes of the whole batch / ranks / step time"}}
+                            "moved_bytes_per_step_per_gpu": b_moved / world,
+                            "frac_on_moved_bytes": b_moved / (step_us * 1e-6) / 1e9 / world / HBM_PEAK_GBS,
+                            "f16_distance": args.f16_distance,
+                            "note": "per GPU: SURVEY 8(d) unfused bytes of the whole batch / ranks / step time; "
+                                    "frac_on_moved_bytes: the bytes the one fused launch actually moves (q, a read once; "
+                                    "dq, da written once) over the same time"}}
+        out["config"]["f16_distance"] = args.f16_distance + (
+            " (scores bit-identical to the fp32 CPU sum of the fp16-rounded inputs)" if args.f16_distance == "ordered"
+            else " (fixed tree sum, ~1e-6 relative; the configuration's bar is 1e-3)")
         print(json.dumps(out), flush=True)
+    capi.set_f16_distance_mode("ordered")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -855,28 +871,39 @@ def run_cfg4(args, torch, dist, capi, world, rank):
     top = torch.empty(m, 1, Wd, Wd, device="cuda")
     full = torch.empty(n, device="cuda")
 
-    def score_local():
-        capi.simcross_forward(1, q, a, top)
-        return top.view(m, -1).amax(dim=1)          # one score per candidate: its best word-pair similarity
+    # every buffer of a step is allocated once: the timed step is launches only (no allocation, no host copy)
+    s_loc = torch.empty(m, device="cuda")
+    prob = torch.zeros(n, 2, device="cuda")          # MAP / MRR read column fixed_axis = 1 only (map_layer.cpp:50)
+    res = torch.empty(2, device="cuda")              # MAP, MRR -- left on the device, like a Layer's Forward_gpu
+    eff = torch.empty(1, dtype=torch.int32, device="cuda")
+    ws = capi.Workspace()
 
     def step():
-        s = score_local()
+        capi.simcross_forward(1, q, a, top)
+        torch.amax(top.view(m, -1), dim=1, out=s_loc)      # one score per candidate: its best word-pair similarity
         if world > 1:
             if args.backend == "nccl":
-                sharded.all_gather_scores(s, n, out=full)
+                sharded.all_gather_scores(s_loc, n, out=full)
             else:
-                full.copy_(sharded.all_gather_scores(s.cpu(), n))
+                full.copy_(sharded.all_gather_scores(s_loc.cpu(), n))
+            prob[:, 1].copy_(full)
         else:
-            full.copy_(s)
-        prob = torch.stack([1 - full, full], 1).contiguous()
-        return capi.rank_map_mrr(prob, label, grp)
+            prob[:, 1].copy_(s_loc)
+        capi.rank_map_mrr_device(prob, label, grp, res, eff, ws=ws)
 
-    # ranking identity: sharded == unsharded, on every rank
-    mp, mrr, eff = step()
+    # ranking identity: sharded == unsharded, on every rank (host copies here, before anything is timed)
+    step()
+    torch.cuda.synchronize()
+    mp, mrr = (float(x) for x in res.tolist())
+    full_now = prob[:, 1].contiguous()
     top_all = torch.empty(n, 1, Wd, Wd, device="cuda")
     capi.simcross_forward(1, qa, aa, top_all)
     ref = top_all.view(n, -1).amax(dim=1)
-    same = bool((full.view(torch.int32) == ref.view(torch.int32)).all().item())
+    same = bool((full_now.view(torch.int32) == ref.view(torch.int32)).all().item())
+    prob_ref = torch.zeros(n, 2, device="cuda")
+    prob_ref[:, 1].copy_(ref)
+    mp_ref, mrr_ref, _ = capi.rank_map_mrr(prob_ref, label, grp)
+    same = same and mp == mp_ref and mrr == mrr_ref
     flag = torch.tensor([1.0 if same else 0.0, mp, -mp, mrr, -mrr], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -890,7 +917,10 @@ def run_cfg4(args, torch, dist, capi, world, rank):
         step()
     main = torch.cuda.current_stream()
     ev_ms, wall_ms = time_regions(torch, dist, world, main, args.repeats, lambda r: [step() for _ in range(K)])
-    t_ms = median(wall_ms)                          # step() ends with a device-to-host copy: host wall is the clock
+    # device-resident steps: HIP events on the launch stream are the clock (the gloo rehearsal stages the gather
+    # through the host, so there the host wall is)
+    device_only = world == 1 or args.backend == "nccl"
+    t_ms = median(ev_ms) if device_only else median(wall_ms)
     if rank == 0:
         out = {"metric": "candidates scored + ranked per second, cfg 4: 1,517 x (40 x 40 x 50) SimCross forward -> "
                          "all-gather -> MAP/MRR",
@@ -902,8 +932,12 @@ def run_cfg4(args, torch, dist, capi, world, rank):
                               dist.get_world_size() if world > 1 else 1,
                           "ranking_identity": "gathered scores bit-identical to the unsharded scoring on every rank; "
                                               "MAP %.6f / MRR %.6f equal on all ranks" % (mp, mrr),
-                          "clock": "host wall inside barrier+synchronize fences (the step ends with a D2H copy), "
-                                   "median of %d repeats" % args.repeats,
+                          "clock": ("HIP events on the launch stream inside barrier+synchronize fences: the step is "
+                                    "launches only -- scoring, per-candidate max, all-gather, MAP/MRR with the results "
+                                    "left on the device; " if device_only else
+                                    "host wall inside barrier+synchronize fences (gloo rehearsal: the gather is staged "
+                                    "through the host); ") + "median of %d repeats" % args.repeats,
+                          "host_wall_ms_per_step_median": median(wall_ms) / K,
                           "parallelism": "pair-sharded x%d, %s" % (
                               world, "RCCL all-gather per step" if args.backend == "nccl" else "gloo rehearsal")}}
         print(json.dumps(out), flush=True)
@@ -1098,12 +1132,20 @@ def other_configs(torch, capi):
     dT = torch.randn(N, 1, 1, 1, device="cuda", generator=g)
     top = torch.empty(N, 1, 1, 1, device="cuda")
     dqh, dah = torch.empty_like(qh), torch.empty_like(ah)
-    us = _graph_time(torch, lambda: capi.simcross_euclid_forward_backward_f16(qh, ah, dT, top, dqh, dah))
     b_unfused = 2 * (3 * N * 2 * D) + 4 * 3 * N                      # SURVEY 8(d), s = 2: 100.7 MB
-    out["cfg5_shard_8192x1024_fp16_storage_fused"] = {
-        "us_per_step": us, "pairs_per_s": N / (us * 1e-6),
-        "frac_hbm_unfused_bytes": b_unfused / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": "hbm",
-        "dtype": "f16 storage / f32 arithmetic"}
+    b_moved = 2 * (2 * N * 2 * D) + 4 * 2 * N                        # what the fused launch moves: 67.2 MB
+    for mode, key in (("ordered", "cfg5_shard_8192x1024_fp16_storage_fused"),
+                      ("tree", "cfg5_shard_8192x1024_fp16_storage_fused_tree")):
+        capi.set_f16_distance_mode(mode)                             # the launcher picks the kernel at capture time
+        us = _graph_time(torch, lambda: capi.simcross_euclid_forward_backward_f16(qh, ah, dT, top, dqh, dah))
+        out[key] = {
+            "us_per_step": us, "pairs_per_s": N / (us * 1e-6),
+            "frac_hbm_unfused_bytes": b_unfused / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "frac_hbm_moved_bytes": b_moved / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": "hbm",
+            "dtype": "f16 storage / f32 arithmetic",
+            "f16_distance": mode + (": the reference's d-ascending fp32 sum, scores bit-identical" if mode == "ordered"
+                                    else ": fixed tree sum, ~1e-6 relative (the configuration's bar is 1e-3)")}
+    capi.set_f16_distance_mode("ordered")
     del qh, ah, dT, top, dqh, dah
     # cfg 4: scoring only -- the TREC-QA test split (1517 candidates, 40 x 40 word grids, Dw = 50),
     # whole and as the 190-candidate shard one of 8 GPUs scores, plus MAP + MRR on 1517 sentence scores

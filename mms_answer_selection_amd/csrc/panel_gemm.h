@@ -86,6 +86,9 @@ struct PanelGeom {
   static constexpr int STAGE_F = B_F + A_F + S_F;
   static constexpr size_t kLdsBytes =
       (3 * (size_t)STAGE_F > 64 * (size_t)LD ? 3 * (size_t)STAGE_F : 64 * (size_t)LD) * sizeof(float);
+  // the hand-issued tile (round 3): operands are read DIST ahead of their MFMA; NOPS MFMAs per tile
+  static constexpr int DIST = 2 * NT - 1 < 16 ? 2 * NT - 1 : 16;
+  static constexpr int NOPS = 8 * NT;
   static_assert(NPT < 60, "vmcnt is a 6-bit counter");
 };
 
@@ -114,6 +117,16 @@ __device__ unsigned long long* pg_stamp_buf = nullptr;
 #else
 #define PG_STAMP(k) do {} while (0)
 #endif
+
+// f(integral_constant<int, I>) for I = 0 .. N-1: the hand-issued tile needs its operand index as a compile-time
+// constant (instruction immediates); a `#pragma unroll` loop only promises that if the unroller agrees
+template <int I, int N, typename F>
+__device__ __forceinline__ void pg_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    pg_static_for<I + 1, N>(f);
+  }
+}
 
 template <int NT, bool A_KC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void panel_gemm_kernel(PanelArgs p) {
@@ -349,6 +362,108 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
 
+  // ---- round 3: the compute waves' tile, HAND-ISSUED -------------------------------------------------------------
+  // tools/mfmastruct.hip (profiles/r03_mfmastruct.txt): every VALU instruction that shares a SIMD with the MFMA
+  // stream -- the loaders' address arithmetic, but just as much the compute wave's OWN LDS address updates, 3-6 per
+  // k-step in the compiler-scheduled tile above -- costs the matrix pipe 8-11 cycles: 32.1 cycles per MFMA for the
+  // bare stream, 34.4 with four VALU instructions per k-step, 39.3 measured in the product loop.  Here the tile has
+  // none: each stage has ONE per-lane base register for B and one for A, every operand is `ds_read_b32 v, base
+  // offset:IMM` (all offsets are compile-time constants below 64 KB), issued exactly DIST = 16 operands ahead of its
+  // MFMA so that `s_waitcnt lgkmcnt(15)` -- the counter has four bits -- in front of an MFMA means "its operand has
+  // landed" (LDS operations return in order), and __builtin_amdgcn_sched_barrier pins the order read, wait, MFMA.
+  // The microbenchmark's loop of exactly this shape runs at 32.1 cycles per MFMA, 34.6 with the ring, the barrier and
+  // the loaders' DMAs beside it.  Operand n = NT st + tt of a tile lives in slot n mod 2 NT.
+#ifndef MMS_PG_HAND
+#define MMS_PG_HAND 1
+#endif
+  float bb[2 * NT];
+  pg_v4f an[2];                                       // A_KC: the next tile's fragments as read
+  float araw[8], sraw[8];                             // !A_KC: the next tile's A values and their k scales as read
+  unsigned bbase[3], abase[3], scbase[3];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) {
+    bbase[s3] = lds_base + (unsigned)(s3 * STAGE_F + 4 * g * LD + r) * 4u;
+    abase[s3] = lds_base + (unsigned)(s3 * STAGE_F + G::B_F + (A_KC ? (wave * 16 + r) * PG_LDA + 4 * g : 4 * g * PG_LDT + wave * 16 + r)) * 4u;
+    scbase[s3] = lds_base + (unsigned)(s3 * STAGE_F + G::B_F + G::A_F + 4 * g) * 4u;
+  }
+  // the three bases ROTATE with the tiles ([0]: the tile being multiplied, [1]: the next one): three register moves per
+  // array per tile instead of a selection by T % 3, which the compiler turned into branches around the tile bodies
+  // and, at their merges, into copies of the whole accumulator set
+  auto hand_rotate = [&]() {
+    unsigned t0 = bbase[0]; bbase[0] = bbase[1]; bbase[1] = bbase[2]; bbase[2] = t0;
+    t0 = abase[0]; abase[0] = abase[1]; abase[1] = abase[2]; abase[2] = t0;
+    if (!A_KC) { t0 = scbase[0]; scbase[0] = scbase[1]; scbase[1] = scbase[2]; scbase[2] = t0; }
+  };
+  auto hand_issue_a = [&](int which) {                // tile [which]'s A operands: asked for, not waited for
+    const unsigned ab = which ? abase[1] : abase[0];
+    if (A_KC) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(an[0]) : "v"(ab) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(an[1]) : "v"(ab) : "memory");
+    } else {
+      const unsigned sb3 = which ? scbase[1] : scbase[0];
+      pg_static_for<0, 8>([&araw, &sraw, ab, sb3](auto hi_tag) {
+        constexpr int hi = decltype(hi_tag)::value;
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(araw[hi]) : "v"(ab), "n"((16 * (hi >> 2) + (hi & 3)) * PG_LDT * 4) : "memory");
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(sraw[hi]) : "v"(sb3), "n"((16 * (hi >> 2) + (hi & 3)) * 4) : "memory");
+      });
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto hand_finish_a = [&]() {                        // behind the A reads AND at most 15 younger LDS operations
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(G::DIST < 16 ? G::DIST : 15) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (A_KC) {
+      av[0] = an[0]; av[1] = an[1];
+    } else {
+#pragma unroll
+      for (int hi = 0; hi < 8; ++hi) av[hi >> 2][hi & 3] = araw[hi] * sraw[hi];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#define MMS_PG_BREAD(base, m)                                                                                          \
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bb[(m) % (2 * NT)]) : "v"(base),                                 \
+               "n"(((16 * (((m) / NT) >> 2) + (((m) / NT) & 3)) * G::LD + 16 * ((m) % NT)) * 4) : "memory")
+  auto hand_prime = [&]() {                           // tile [0] has landed: its A operands and its first G::DIST B operands
+    hand_issue_a(0);
+    const unsigned bc = bbase[0];
+    pg_static_for<0, G::DIST>([&bb, bc](auto m_tag) {
+      constexpr int m = decltype(m_tag)::value;
+      MMS_PG_BREAD(bc, m);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    hand_finish_a();
+  };
+  // A full tile whose A operands and first G::DIST B operands have been asked for.  BAR: tile T+1 exists -- its barrier
+  // sits in front of MFMA G::NOPS - G::DIST, where every read of this tile has been issued (and is awaited: the loaders
+  // overwrite this stage next).  PRE: tile T+1 is a full tile: its A operands and first G::DIST B operands are asked for
+  // beside the last G::DIST MFMAs of this one.
+  auto hand_tile = [&](auto bar_tag, auto pre_tag) {
+    constexpr bool BAR = decltype(bar_tag)::value, PRE = decltype(pre_tag)::value;
+    const unsigned bc = bbase[0], bn = bbase[1];
+    __builtin_amdgcn_sched_barrier(0);
+    pg_static_for<0, G::NOPS>([&acc, &av, &bb, &hand_issue_a, bc, bn](auto n_tag) {
+      constexpr int n = decltype(n_tag)::value;
+      if (BAR && n == G::NOPS - G::DIST) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");               // B_{T+1}
+        __builtin_amdgcn_sched_barrier(0);
+        if (PRE) hand_issue_a(1);
+      }
+      if (!(BAR && n >= G::NOPS - G::DIST)) {               // (behind the barrier's wait every operand of this tile is there)
+        // younger reads in front of MFMA n: G::DIST - 1 while the stream runs, fewer at the end of a tile without successor
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(G::NOPS - 1 - n < G::DIST - 1 ? G::NOPS - 1 - n : G::DIST - 1) : "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[n % NT] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(n / NT) >> 2][(n / NT) & 3], bb[n % (2 * NT)], acc[n % NT], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (n + G::DIST < G::NOPS) MMS_PG_BREAD(bc, n + G::DIST);
+      else if (PRE) MMS_PG_BREAD(bn, n + G::DIST - G::NOPS);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (PRE) hand_finish_a();
+    hand_rotate();
+  };
+#undef MMS_PG_BREAD
+
   // ---- main loop: three-stage ring, one barrier per 32-deep k-tile -----------------------------------
   // Both roles execute EXACTLY ntiles + 2 workgroup barriers (B_0 .. B_{ntiles-1}, B_end, B_stage).
   // Loader invariant at the top of iteration T: tiles T and T+1 have been issued (NPT DMAs per wave each, in
@@ -432,6 +547,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #ifdef MMS_PG_STAMPS
     unsigned long long ld_wait = 0, ld_bar = 0, ld_issue = 0;
 #endif
+    const int SP = ntiles >= 8 ? 2 : 1;               // side-job passes: requested in iteration SP rr, stored one later
+    int s_loaded = 0, s_stored = 0;
     for (int T = 0; T < ntiles; ++T) {
 #ifdef MMS_PG_STAMPS
       const unsigned long long l0 = __builtin_amdgcn_s_memtime();
@@ -444,8 +561,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPT) : "memory");       // B_T
 #endif
       if (p.side_in) {
-        if (T >= 1 && T <= 4) { side_pin(); side_store(T - 1); }
-        if (T < 4) side_load(T);
+        // round 3: one row pass every SPth iteration instead of the first four -- 256 workgroups streaming their
+        // 2 x 77 KB at the same moment, in front of their own first tiles, cost the launch 3-4 us
+        if (s_stored < s_loaded && T >= SP * s_stored + 1) { side_pin(); side_store(s_stored); ++s_stored; }
+        if (s_loaded < 4 && s_loaded == s_stored && T >= SP * s_loaded) { side_load(s_loaded); ++s_loaded; }
       }
 #if defined(MMS_PG_ABLATE) && MMS_PG_ABLATE >= 1      // dev-only timing ablation (tools/panelbench.hip): no loads after the prologue
       if (false)
@@ -463,12 +582,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #endif
     if (p.side_in) {                                  // what the loop was too short for
-      const int done_load = ntiles < 4 ? ntiles : 4;
-      const int done_store = (ntiles < 5 ? ntiles : 5) > 0 ? (ntiles < 5 ? ntiles : 5) - 1 : 0;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       side_pin();
-      if (done_store < done_load) side_store(done_load - 1);
-      for (int rr = done_load; rr < 4; ++rr) {
+      if (s_stored < s_loaded) { side_store(s_stored); ++s_stored; }
+      for (int rr = s_loaded; rr < 4; ++rr) {
         side_load(rr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         side_pin();
@@ -480,6 +597,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int T = 0;
     PG_STAMP(0);
     if (ntiles > 0) asm volatile("s_barrier" ::: "memory");                              // B_0
+#if MMS_PG_HAND && !defined(MMS_PG_ABLATE)
+    // Same-box A/B (gpurun_out/r3/ab_hand.txt, three alternations): the hand-issued tile is worth 2.4 us on the
+    // split-K dW product (38.7 -> 36.3 us), nothing on Q.W (40.1 / 40.4) and COSTS 1.8 us where the loaders carry
+    // the da side job (36.6 -> 38.4) -- the launch is then power-bound: the shader clock falls from 2.18 to 2.10 GHz
+    // as the stream tightens (stamps).  So it serves the !A_KC product only; MMS_PG_HAND=2 forces it everywhere.
+    if (p.nseg == 1 && (!A_KC || MMS_PG_HAND >= 2)) {
+      // one segment (every product of cfg 3): all full tiles that are followed by a full tile run in ONE loop body
+      if (nfull > 0) {
+        hand_prime();
+        for (int f = 0; f + 1 < nfull; ++f) hand_tile(std::true_type{}, std::true_type{});
+        if (has_tail) hand_tile(std::true_type{}, std::false_type{});
+        else hand_tile(std::false_type{}, std::false_type{});
+      }
+      if (has_tail) tail_tile(nfull % 3, kbeg + 32 * nfull);
+      T = ntiles;
+    } else
+#endif
+    {
     bool primed = false;                               // are tile T's first operands in registers?
     for (int seg = 0; seg < p.nseg; ++seg) {
       int k0 = kbeg;
@@ -501,6 +636,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (T < ntiles) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B_T of the next segment's first tile
         primed = false;
       }
+    }
     }
     PG_STAMP(1);
   }

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
+#include <type_traits>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -17,7 +18,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // tile from an L2-resident buffer; 16 = operand reads walk a three-stage ring (stage = tile % 3) instead of one image;
 // 32 = partners' VALU ops at priority 0; 64 = compute waves at priority 2; 128 = the compute wave itself issues 4 VALU
 // ops per k-step (LDS address updates); 256 = accumulators ping-pong between two register sets (vDst != SrcC, as the
-// compiler allocates them in the product kernels); 512 = A operand re-read from LDS every 4 k-steps (ds_read_b128)
+// compiler allocates them in the product kernels); 512 = A operand re-read from LDS every 4 k-steps (ds_read_b128);
+// 1024 = the operand reads are hand-issued `ds_read_b32 v, vbase offset:IMM` from ONE per-stage base register (no
+// address arithmetic in the loop at all), each MFMA behind `s_waitcnt lgkmcnt(18)` tied to its operand register
 template <int FLAGS>
 __global__ __launch_bounds__(512) void struct_kernel(float* out, unsigned long long* stamps, const float* src, int iters) {
   extern __shared__ float lds[];                       // 3 x 13376 floats
@@ -67,6 +70,47 @@ __global__ __launch_bounds__(512) void struct_kernel(float* out, unsigned long l
   for (int i = 0; i < 19; ++i) acc2[i] = (v4f){0.f, 0.f, 0.f, 0.f};
   int vx = lane;
   v4f a4 = (v4f){a, a, a, a};
+  if (FLAGS & 1024) {
+    // hand-issued stream: stage bases in three registers, everything else immediate
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+    unsigned sbase[3];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) sbase[s3] = lds_base + (unsigned)(s3 * STAGE + (lane & 15) + 308 * 4 * (lane >> 4)) * 4u;
+    const unsigned long long t0h = __builtin_amdgcn_s_memtime(), r0h = __builtin_amdgcn_s_memrealtime();
+    // operand n of a tile (n = 19 st + tt) lives in slot n mod 38; its read is issued right behind MFMA n - 16, so
+    // that in front of MFMA n exactly the reads n+1 .. n+15 are younger: `s_waitcnt lgkmcnt(15)` (a 4-bit counter)
+    float bb[38];
+#pragma unroll
+    for (int i = 0; i < 38; ++i) bb[i] = 0.25f;
+    for (int it = 0; it < iters; ++it) {
+      const int s3 = it % 3, n3 = (it + 1) % 3;
+      const unsigned base = RING ? (s3 == 0 ? sbase[0] : s3 == 1 ? sbase[1] : sbase[2]) : sbase[0];
+      const unsigned nbase = RING ? (n3 == 0 ? sbase[0] : n3 == 1 ? sbase[1] : sbase[2]) : sbase[0];
+#pragma unroll
+      for (int n = 0; n < 152; ++n) {
+        if (BAR && n == 133) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        acc[n % 19] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb[n % 38], acc[n % 19], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int m = n + 16;
+        if (m < 152) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bb[m % 38]) : "v"(base), "n"((((m / 19) & 7) * 308 + 16 * (m % 19)) * 4) : "memory");
+        else asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bb[m % 38]) : "v"(nbase), "n"(((((m - 152) / 19) & 7) * 308 + 16 * ((m - 152) % 19)) * 4) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t1h = __builtin_amdgcn_s_memtime(), r1h = __builtin_amdgcn_s_memrealtime();
+    float sh = 0.f;
+#pragma unroll
+    for (int i = 0; i < 19; ++i) sh += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + bb[i] + bb[i + 19];
+    if (sh == 12345.678f) out[t] = sh;
+    if (lane == 0) {
+      const size_t w = (size_t)blockIdx.x * 4 + wave;
+      stamps[2 * w] = t1h - t0h;
+      stamps[2 * w + 1] = r1h - r0h;
+    }
+    return;
+  }
   for (int it = 0; it < iters; ++it) {
     const float* p = RING ? p0 + (it % 3) * STAGE : p0;
 #pragma unroll
@@ -155,5 +199,8 @@ int main() {
   run<512>("stream + A operand re-read from LDS", src);
   run<128 | 256 | 512>("stream + own VALU + ping-pong + A re-read", src);
   run<1 | 2 | 8 | 16 | 128 | 256 | 512>("all of the above + barrier + partner DMAs (no partner VALU) + ring", src);
+  run<1024>("HAND-ISSUED stream: ds_read_b32 base + immediate, waits tied to operands", src);
+  run<1024 | 16>("hand-issued + ring (base selected per tile)", src);
+  run<1024 | 16 | 1 | 2 | 8>("hand-issued + ring + barrier + partner DMAs (no partner VALU)", src);
   return 0;
 }
