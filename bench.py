@@ -81,7 +81,7 @@ def parse():
                    help="graph: steps captured into hipGraphs of --group steps; eager: every kernel launched by "
                         "itself through pre-bound C-ABI calls, the way a native Layer host does (a hipGraphLaunch "
                         "costs 6.5 us of device time, a third of a microsecond per step in the driver's 20-step "
-                        "regions); auto = eager for the layers path when --steps < 1024, graph otherwise")
+                        "regions) -- host-paced, so only as good as the host is idle; auto = graph")
     p.add_argument("--f16-distance", choices=["ordered", "tree"], default="ordered",
                    help="--workload cfg5: 'ordered' = the reference's d-ascending fp32 sum of the 1024 squares, scores "
                         "bit-identical to the fp32 CPU code on the fp16-rounded inputs; 'tree' = fixed-shape tree sum, "
@@ -467,7 +467,13 @@ def run(args):
     # auto: short regions (the driver's --steps 20) launch kernel by kernel -- one hipGraphLaunch per region would cost
     # 6.5 us of device time, a third of a microsecond per step (8.05-8.11 vs 7.71 us); long regions keep hipGraphs of
     # --group steps, where the host never has to keep pace (7.57 us in every repeat vs 7.6-8.2 eager)
-    eager = args.no_graph or args.launch == "eager" or (args.launch == "auto" and raw_step is not None and K < 1024)
+    # round 3: `auto` is ALWAYS hipGraphs of up to --group steps (the driver's --steps 20 is one graph per region).
+    # Round 2 launched short regions kernel by kernel from the host (7.6-7.8 us per step when the host kept pace); a
+    # round-3 run on a busier box had the host fall behind in two of five repeats (13 us per step) and a median of
+    # 9.8 us: a host-paced number is not a measurement of the kernels.  A graph region costs one hipGraphLaunch
+    # (~6.5 us of device time, a third of a microsecond per step at K = 20) and nothing else depends on the host;
+    # `roofline.long_region` still reports the same walk over 2048 steps.  `--launch eager` keeps the other mode.
+    eager = args.no_graph or args.launch == "eager"
     use_graph = not eager
     reg = Region(torch, step, ring, G, buckets, use_graph, raw_step)
 
@@ -1075,6 +1081,42 @@ def other_configs(torch, capi):
     out["cfg3_simmatrix_recomputing_backward"] = {
         "us_per_step": us, "pairs_per_s": N / (us * 1e-6), "TFLOPs": flops / us / 1e6,
         "frac_mfma_fp32_peak": flops / (us * 1e-6) / 157.3e12, "bound": "mfma", "dtype": "f32"}
+
+    # the fused learned-metric TRIPLET step (round 3): SimMatrix(q, a+), SimMatrix(q, a-) with W shared -> PairRankLoss,
+    # forward and backward, as one call = three products (Q.W once, dq = B.W^T, dW += Q^T.B) with the hinge and its
+    # gradient in the first product's epilogue -- next to the same net run layer by layer through the C ABI
+    an = rnd(N, K)
+    yl = (torch.rand(N, 1, device="cuda", generator=g) < 0.8).float()
+    sp, sn, ls = torch.empty(N, 1, device="cuda"), torch.empty(N, 1, device="cuda"), torch.empty(1, device="cuda")
+    dan, dq2, scr2 = torch.empty_like(a), torch.empty_like(q), torch.empty(N, K, device="cuda")
+    po, ps, gsp, gsn = (torch.empty(N, 1, device="cuda") for _ in range(4))
+    ws2 = capi.Workspace()
+
+    def trip_fused():
+        capi.triplet_simmatrix_step(q, a, an, yl, W, sp, sn, ls, dq, da, dan, dW, margin=0.3, ws=ws2)
+    us = _graph_time(torch, trip_fused, iters=16)
+    done3 = 3 * 2.0 * N * K * K
+    credited = 2 * (2.0 * N * K * K + 2.0 * N * K) + 2 * 6.0 * N * K * K     # two SimMatrix layers, fwd + bwd
+    out["cfg3_triplet_simmatrix_16384x300x300_fused_step"] = {
+        "us_per_step": us, "triplets_per_s": N / (us * 1e-6), "executed_TFLOPs": done3 / us / 1e6,
+        "executed_frac_mfma_fp32_peak": done3 / (us * 1e-6) / 157.3e12,
+        "TFLOPs_credited_layer_by_layer": credited / us / 1e6, "bound": "mfma", "dtype": "f32",
+        "note": "mms_triplet_simmatrix_step_f32: 3 products executed (8.85 GFLOP) for the 8 the two layers' forward + "
+                "backward are credited with (23.6 GFLOP)"}
+
+    def trip_layers():
+        capi.simmatrix_forward(q, a, W, sp, scr)
+        capi.simmatrix_forward(q, an, W, sn, scr2)
+        capi.pairrank_forward(sp, sn, yl, po, ps, ls, margin=0.3, ws=ws)
+        capi.pairrank_backward(yl, po, ps, gsp, gsn)
+        capi.simmatrix_backward(q, a, W, gsp, dq, da, dW, ws=ws, qw=scr)
+        capi.simmatrix_backward(q, an, W, gsn, dq2, dan, dW, ws=ws, qw=scr2)
+    us = _graph_time(torch, trip_layers, iters=8)
+    out["cfg3_triplet_simmatrix_layer_by_layer"] = {
+        "us_per_step": us, "triplets_per_s": N / (us * 1e-6), "TFLOPs_credited_layer_by_layer": credited / us / 1e6,
+        "note": "the same net through the per-layer entry points (8 launches of products + PairRankLoss fwd/bwd; "
+                "dq's Split sum not included)"}
+    del an, yl, sp, sn, ls, dan, dq2, scr2, po, ps, gsp, gsn
 
     # the same arithmetic written as a SimCross layer: dist_mode 2, one measure, W1 = W2 = 1 (bias_term false, like
     # SimMatrix; with the scalar bias its gradient -- an n-ordered sum of 16384 terms, one dependent chain -- adds ~120 us)

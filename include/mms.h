@@ -333,6 +333,30 @@ size_t mms_triplet_workspace_bytes(int N);
 int mms_triplet_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Fused training step of the LEARNED metric (cfg 3's arithmetic):
+ *   s_pos_i = q_i^T W a_pos_i, s_neg_i = q_i^T W a_neg_i          SimMatrix x 2, W shared (sim_matrix_layer.cpp:53-65)
+ *   loss = PairRankLoss(s_pos, s_neg, y)                            (pair_rank_loss_layer.cpp:26-52)
+ *   backward through PairRankLoss (:55-84) and both SimMatrix layers (sim_matrix_layer.cpp:68-95):
+ *   dq = dq(pos) + dq(neg) (Net::Init's Split sum), da_pos, da_neg, dW += both branches' q_i a_i^T terms (param
+ *   diffs accumulate, as in the layers).
+ * Equivalent net: two SimMatrix layers with bottom q in common and `param { name }` in common, feeding PairRankLoss.
+ * Three products instead of the layers' six: Q W once for both branches -- its epilogue forms both scores, the hinge
+ * term and its gradients g+, g- per row, and writes da_pos = g+ (W^T q), da_neg = g- (W^T q) and B = g+ a_pos + g- a_neg;
+ * then dq = B W^T and dW += Q^T B.  Neither Q W nor the (N, 1) score gradients reach HBM.  Scores, loss terms and
+ * hinge decisions follow the reference's operation order given the scores; everything that passes through a product
+ * agrees with the layer-by-layer result to 1e-5 (the reference's own products go through CBLAS).
+ * Shapes the panel kernel does not serve (K2 > 304, sizes not multiples of 4, small N) run the layers one by one
+ * inside the call: same results, no fusion.  `loss` may be NULL.  dW is accumulated into (zero it like
+ * Net::ClearParamDiffs does).  workspace: mms_triplet_simmatrix_workspace_bytes(N, K1, K2), no initialisation needed.
+ * ------------------------------------------------------------------------- */
+size_t mms_triplet_simmatrix_workspace_bytes(int N, int K1, int K2);
+int mms_triplet_simmatrix_step_f32(int N, int K1, int K2, float margin, float loss_weight,
+                                   const float* q, const float* a_pos, const float* a_neg, const float* y,
+                                   const float* W, float* s_pos, float* s_neg, float* loss,
+                                   float* dq, float* da_pos, float* da_neg, float* dW,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Ranking metrics over the scores (forward only).  These
  * define "ranking output": with the Euclidean scores bit-identical to the CPU
  * code, MAP/MRR/AUC computed here are bit-identical too wherever the sort order

@@ -36,6 +36,8 @@ _SIGNATURES = {
     "mms_pairrank_backward_f32": (_i, [_i, _f] + [_vp] * 3 + [_i, _i] + [_vp] * 3),
     "mms_triplet_workspace_bytes": (_sz, [_i]),
     "mms_triplet_workspace_init": (_i, [_vp, _sz, _vp]),
+    "mms_triplet_simmatrix_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mms_triplet_simmatrix_step_f32": (_i, [_i, _i, _i, _f, _f] + [_vp] * 12 + [_vp, _sz, _vp]),
     "mms_triplet_euclid_step_f32": (_i, [_i, _i, _f, _f] + [_vp] * 11 + [_sz, _vp]),
     "mms_simcross_euclid_forward_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "mms_simcross_euclid_forward_backward_f16": (_i, [_i, _i] + [_vp] * 7),
@@ -307,6 +309,19 @@ def triplet_euclid_step(q, a_pos, a_neg, y, s_pos, s_neg, loss, dq, da_pos, da_n
         _ptr(a_neg, "a_neg"), _ptr(y, "y"), _ptr(s_pos, "s_pos"), _ptr(s_neg, "s_neg"),
         _ptr(loss, "loss", True), _ptr(dq, "dq"), _ptr(da_pos, "da_pos"), _ptr(da_neg, "da_neg"),
         wsp, wsb, _stream()), "mms_triplet_euclid_step_f32")
+
+
+def triplet_simmatrix_step(q, a_pos, a_neg, y, W, s_pos, s_neg, loss, dq, da_pos, da_neg, dW, margin=1.0,
+                           loss_weight=1.0, ws=None):
+    """The fused learned-metric step (include/mms.h: mms_triplet_simmatrix_step_f32).  dW is ACCUMULATED into."""
+    N, K1 = q.shape
+    K2 = a_pos.shape[1]
+    wsp, wsb = (ws or _default_ws).get(lib().mms_triplet_simmatrix_workspace_bytes(N, K1, K2), q.device)
+    check(lib().mms_triplet_simmatrix_step_f32(
+        N, K1, K2, float(margin), float(loss_weight), _ptr(q, "q"), _ptr(a_pos, "a_pos"), _ptr(a_neg, "a_neg"),
+        _ptr(y, "y"), _ptr(W, "W"), _ptr(s_pos, "s_pos"), _ptr(s_neg, "s_neg"), _ptr(loss, "loss", True),
+        _ptr(dq, "dq"), _ptr(da_pos, "da_pos"), _ptr(da_neg, "da_neg"), _ptr(dW, "dW"), wsp, wsb, _stream()),
+        "mms_triplet_simmatrix_step_f32")
 
 
 def rank_map_mrr(prob, label, group, fixed_axis=1, ws=None):

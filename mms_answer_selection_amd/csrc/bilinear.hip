@@ -1676,4 +1676,79 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
   return launch_status();
 }
 
+// ------------------------- fused learned-metric triplet step (round 3) -------------------------
+// The net  SimMatrix(q, a+) , SimMatrix(q, a-)  (W shared by parameter name) -> PairRankLoss, forward and backward, as
+// THREE products instead of the layers' six (sim_matrix_layer.cpp:53-95 twice, pair_rank_loss_layer.cpp:26-84):
+//   P = Q W is the same for both branches: one product, whose epilogue takes both row dots s+ = P_i . a+_i and
+//   s- = P_i . a-_i, PairRankLoss's term and gradients g+, g- for the row, and writes da+ = g+ P_i, da- = g- P_i
+//   (sim_matrix_layer.cpp:88, Trans) and B_i = g+ a+_i + g- a-_i;
+//   dq = B W^T   (the Split sum of the two branches' dq_i = g W a_i, :88 NoTrans, as one product);
+//   dW += Q^T B  (the two branches' sum_i g_i q_i a_i^T, :73-80, as one split-K product).
+// Neither P nor the (N, 1) score gradients reach HBM.
+int triplet_loss_from_terms(const float* terms, int N, float* loss, hipStream_t s);
+int pairrank_hinge_mode();
+
+struct TripSimWs {
+  size_t b_off, terms_off, ones_off, wt_off, part_off, total;
+  int ksplit, kchunk;
+};
+static TripSimWs tripsim_ws(int N, int K1, int K2) {
+  TripSimWs w{};
+  w.ksplit = panel_pick_ksplit((K1 + 63) / 64, 1, N, &w.kchunk);
+  size_t o = 0;
+  auto take = [&](size_t b) { size_t at = o; o += round_up(b, 256); return at; };
+  w.b_off = take((size_t)N * K2 * sizeof(float));
+  w.terms_off = take((size_t)N * sizeof(float));
+  w.ones_off = take((size_t)N * sizeof(float));
+  w.wt_off = take((size_t)K1 * K2 * sizeof(float));
+  w.part_off = take((size_t)(w.ksplit > 0 ? w.ksplit : 1) * K1 * K2 * sizeof(float));
+  w.total = o;
+  return w;
+}
+size_t triplet_simmatrix_workspace_bytes(int N, int K1, int K2) { return tripsim_ws(N, K1, K2).total; }
+
+// MMS_ERR_UNSUPPORTED when the shapes are outside the panel kernel (the caller then runs the layers one by one)
+int triplet_simmatrix_step(int N, int K1, int K2, float margin, float loss_weight, const float* q, const float* ap,
+                           const float* an, const float* y, const float* W, float* s_pos, float* s_neg, float* loss,
+                           float* dq, float* dap, float* dan, float* dW, void* ws, size_t ws_bytes, hipStream_t s) {
+  const TripSimWs lay = tripsim_ws(N, K1, K2);
+  if (!ws || ws_bytes < lay.total) return MMS_ERR_WORKSPACE;
+  char* base = static_cast<char*>(ws);
+  float* B = reinterpret_cast<float*>(base + lay.b_off);
+  float* terms = reinterpret_cast<float*>(base + lay.terms_off);
+  float* ones = reinterpret_cast<float*>(base + lay.ones_off);
+  float* Wt = reinterpret_cast<float*>(base + lay.wt_off);
+  float* part = reinterpret_cast<float*>(base + lay.part_off);
+  const float scale = loss_weight / (float)N;                       // pair_rank_loss_layer.cpp:64, count = N * 1
+  // P = Q W with the triplet epilogue
+  PanelArgs p1 = panel_args(N, K2, K1, q, K1, W, K2, nullptr, K2);
+  p1.Y = ap; p1.Y2 = an; p1.ldy = K2; p1.rowdot = s_pos; p1.rd_stride = 1;
+  p1.trip_y = y; p1.trip_margin = margin; p1.trip_s0 = -1.0f * scale; p1.trip_s1 = 1.0f * scale;
+  p1.trip_hinge_ge = pairrank_hinge_mode() == MMS_PAIRRANK_HINGE_GPU ? 1 : 0;
+  p1.trip_sneg = s_neg; p1.trip_terms = terms; p1.trip_dapos = dap; p1.trip_daneg = dan; p1.trip_b = B;
+  // dq = B W^T  (B(k, n) = W[n][k] = Wt[k][n])
+  PanelArgs p2 = panel_args(N, K1, K2, B, K2, Wt, K1, dq, K1);
+  p2.stream_c = 1;
+  // dW += Q^T B, split over the pairs
+  PanelArgs p3 = panel_args(K1, K2, N, q, K1, B, K2, part, K2);
+  p3.kscale = ones;
+  p3.ksplit = lay.ksplit; p3.kchunk = lay.kchunk; p3.c_ks = (long long)K1 * K2;
+  if (!panel_eligible(p1, true) || !panel_eligible(p2, true) || p3.ksplit <= 1 || !panel_eligible(p3, false))
+    return MMS_ERR_UNSUPPORTED;
+  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ones), 0x3f800000, (size_t)N, s) != hipSuccess) return MMS_ERR_LAUNCH;
+  panel_launch(p1, true, s);
+  if (loss) {
+    const int rc = triplet_loss_from_terms(terms, N, loss, s);
+    if (rc != MMS_OK) return rc;
+  }
+  panel_launch(p3, false, s);
+  {
+    const unsigned rb = ew_blocks((long long)K1 * K2), tb = (unsigned)(((K2 + 31) / 32) * ((K1 + 31) / 32));
+    hipLaunchKernelGGL(splitk_reduce_transpose_kernel, dim3(rb + tb), dim3(256), 0, s, part, p3.ksplit,
+                       (long long)K1 * K2, dW, 1, (int)rb, W, Wt, K1, K2);
+  }
+  panel_launch(p2, true, s);
+  return launch_status();
+}
+
 }  // namespace mms

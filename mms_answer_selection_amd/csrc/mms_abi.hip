@@ -37,6 +37,10 @@ int embed_simcross_forward(int mode, int N, int W1, int W2, int D, int K, const 
 int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, const float* W,
                        const float* top_diff, int ppd, int pd0, int pd1, float* dq, float* da,
                        float* dW, const float* qw, void* ws, size_t ws_bytes, hipStream_t s);
+size_t triplet_simmatrix_workspace_bytes(int N, int K1, int K2);
+int triplet_simmatrix_step(int N, int K1, int K2, float margin, float loss_weight, const float* q, const float* ap,
+                           const float* an, const float* y, const float* W, float* s_pos, float* s_neg, float* loss,
+                           float* dq, float* dap, float* dan, float* dW, void* ws, size_t ws_bytes, hipStream_t s);
 // pairrank.hip
 size_t pairrank_workspace_bytes(int count);
 int pairrank_forward(int count, float margin, const float* a, const float* b, const float* y,
@@ -353,6 +357,61 @@ int mms_pairrank_backward_f32(int count, float top_diff, const float* y, const f
   if ((propagate_down0 && !da) || (propagate_down1 && !db)) return MMS_ERR_INVALID_ARG;
   return pairrank_backward(count, top_diff, y, ordered, similar, propagate_down0 ? da : nullptr,
                            propagate_down1 ? db : nullptr, as_stream(stream));
+}
+
+// ---- fused learned-metric triplet step ----------------------------------------------------------------------------
+namespace {
+struct TripSimSlow {                                  // the layers one by one, inside the call (shapes outside the fast path)
+  size_t qwp, qwn, ord, sim, gsp, gsn, dq2, lossf, prws, smws, total;
+};
+TripSimSlow tripsim_slow_layout(int N, int K1, int K2) {
+  TripSimSlow w{};
+  size_t o = 0;
+  auto take = [&](size_t b) { size_t at = o; o += mms::round_up(b, 256); return at; };
+  w.qwp = take((size_t)N * K2 * 4); w.qwn = take((size_t)N * K2 * 4);
+  w.ord = take((size_t)N * 4); w.sim = take((size_t)N * 4); w.gsp = take((size_t)N * 4); w.gsn = take((size_t)N * 4);
+  w.dq2 = take((size_t)N * K1 * 4); w.lossf = take(256);
+  w.prws = take(mms::pairrank_workspace_bytes(N)); w.smws = take(mms::simmatrix_workspace_bytes(N, K1, K2));
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+size_t mms_triplet_simmatrix_workspace_bytes(int N, int K1, int K2) {
+  if (N <= 0 || K1 <= 0 || K2 <= 0) return 0;
+  const size_t fast = mms::triplet_simmatrix_workspace_bytes(N, K1, K2), slow = tripsim_slow_layout(N, K1, K2).total;
+  return fast > slow ? fast : slow;
+}
+
+int mms_triplet_simmatrix_step_f32(int N, int K1, int K2, float margin, float loss_weight, const float* q,
+                                   const float* a_pos, const float* a_neg, const float* y, const float* W,
+                                   float* s_pos, float* s_neg, float* loss, float* dq, float* da_pos, float* da_neg,
+                                   float* dW, void* workspace, size_t workspace_bytes, void* stream) {
+  if (N <= 0 || K1 <= 0 || K2 <= 0 || (long long)N * K1 > 0x7fffffffLL || (long long)N * K2 > 0x7fffffffLL)
+    return MMS_ERR_INVALID_ARG;
+  if (!q || !a_pos || !a_neg || !y || !W || !s_pos || !s_neg || !dq || !da_pos || !da_neg || !dW)   // loss may be NULL
+    return MMS_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < mms_triplet_simmatrix_workspace_bytes(N, K1, K2)) return MMS_ERR_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  const int rc = mms::triplet_simmatrix_step(N, K1, K2, margin, loss_weight, q, a_pos, a_neg, y, W, s_pos, s_neg, loss,
+                                             dq, da_pos, da_neg, dW, workspace, workspace_bytes, s);
+  if (rc != MMS_ERR_UNSUPPORTED) return rc;
+  // layer by layer: SimMatrix x 2 -> PairRankLoss -> PairRankLoss backward -> SimMatrix backward x 2 -> Split sum
+  const TripSimSlow lay = tripsim_slow_layout(N, K1, K2);
+  char* base = static_cast<char*>(workspace);
+  auto f = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+  int r = mms::simmatrix_forward(N, K1, K2, q, a_pos, W, s_pos, f(lay.qwp), s, nullptr);
+  if (r == MMS_OK) r = mms::simmatrix_forward(N, K1, K2, q, a_neg, W, s_neg, f(lay.qwn), s, nullptr);
+  if (r == MMS_OK) r = mms::pairrank_forward(N, margin, s_pos, s_neg, y, f(lay.ord), f(lay.sim), loss ? loss : f(lay.lossf),
+                                            base + lay.prws, mms::pairrank_workspace_bytes(N), s);
+  if (r == MMS_OK) r = mms::pairrank_backward(N, loss_weight, y, f(lay.ord), f(lay.sim), f(lay.gsp), f(lay.gsn), s);
+  if (r == MMS_OK) r = mms::simmatrix_backward(N, K1, K2, q, a_pos, W, f(lay.gsp), 1, 1, 1, dq, da_pos, dW, f(lay.qwp),
+                                              base + lay.smws, mms::simmatrix_workspace_bytes(N, K1, K2), s);
+  if (r == MMS_OK) r = mms::simmatrix_backward(N, K1, K2, q, a_neg, W, f(lay.gsn), 1, 1, 1, f(lay.dq2), da_neg, dW, f(lay.qwn),
+                                              base + lay.smws, mms::simmatrix_workspace_bytes(N, K1, K2), s);
+  if (r != MMS_OK) return r;
+  const float* two[2] = {dq, f(lay.dq2)};
+  return mms_split_backward_f32(N * K1, 2, two, dq, stream);
 }
 
 size_t mms_triplet_workspace_bytes(int N) { return N > 0 ? triplet_workspace_bytes(N) : 0; }

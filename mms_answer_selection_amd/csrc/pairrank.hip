@@ -17,6 +17,7 @@
 #include <cstring>
 
 #include "euclid_math.h"
+#include "pairrank_math.h"
 #include "mms_common.h"
 
 namespace mms {
@@ -48,34 +49,6 @@ void set_loss_sum_mode(int m) { t_loss_sum = m; }
 static thread_local int t_triplet_finish = MMS_TRIPLET_FINISH_INLAUNCH;
 int triplet_finish_mode() { return t_triplet_finish; }
 void set_triplet_finish_mode(int m) { t_triplet_finish = m; }
-
-struct PairTerm {
-  float ordered, similar, term;
-};
-
-// :28-37 and the summand of :43-44, in the reference's operation order.
-__device__ __forceinline__ PairTerm pair_term(float a, float b, float y, float margin) {
-  PairTerm p;
-  const float diff = a - b;          // caffe_sub
-  p.similar = diff;                  // caffe_copy
-  float o = diff * y;                // caffe_mul
-  o = -1.0f * o + 0.0f * o;          // caffe_cpu_axpby(-1, x, 0, y = x) (MKL semantics)
-  o = o + margin;                    // caffe_add_scalar
-  p.ordered = o;
-  const float hinge = (0.0f < o) ? o : 0.0f;  // std::max(Dtype(0), o)
-  p.term = hinge + fabsf((1.0f - y) * diff);
-  return p;
-}
-
-// :72-79 for one element; s0/s1 are the two `sign` values.
-__device__ __forceinline__ void pair_grad(float y, float ordered, float similar, float s0,
-                                          float s1, float& ga, float& gb, bool ge = false) {
-  const float ordered_t = (ge ? ordered >= 0.0f : ordered > 0.0f) ? 1.0f : 0.0f;
-  const float similar_t = (1.0f - y) * similar > 0.0f ? 1.0f : -1.0f;
-  const float inner = ordered_t * y - similar_t * (1.0f - y);
-  ga = s0 * inner;
-  gb = s1 * inner;
-}
 
 constexpr int kPairThreads = 256;
 
@@ -938,6 +911,17 @@ int triplet_euclid_step(int N, int D, float margin, float loss_weight, const flo
   else
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kPairThreads), 0, s, partials, nparts, N,
                        loss);
+  return launch_status();
+}
+
+// loss = (sum of the N per-triplet terms) / N from a device array of terms: the tail of both fused steps
+// (pair_rank_loss_layer.cpp:41-49).  MMS_LOSS_SUM_REFERENCE: the reference's running fp32 sum, else the fixed tree.
+int triplet_loss_from_terms(const float* terms, int N, float* loss, hipStream_t s) {
+  if (loss_sum_mode() == MMS_LOSS_SUM_REFERENCE)
+    hipLaunchKernelGGL(loss_running_sum_kernel, dim3(1), dim3(256), 0, s, terms, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, N, loss);
+  else
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kPairThreads), 0, s, terms, N, N, loss);
   return launch_status();
 }
 

@@ -43,6 +43,7 @@
 #include <type_traits>
 
 #include "mms_common.h"
+#include "pairrank_math.h"
 
 namespace mms {
 
@@ -65,6 +66,13 @@ struct PanelArgs {
   // side job of the loader waves (ksplit == 1, nb == 1): side_out(i,:) = side_scale[i] * side_in(i,:) for the
   // M rows of the product, side_cols (% 4 == 0, <= 16*NT) floats per row; side_out may be side_in
   const float* side_in; float* side_out; const float* side_scale; long long side_ld; int side_cols;
+  // fused learned-metric triplet step (A_KC, ksplit == 1, nb == 1; round 3): the product is P = Q W, Y = A+ and Y2 = A-.
+  // The epilogue forms both row dots s+ = P_i . a+_i (-> rowdot) and s- = P_i . a-_i (-> trip_sneg), PairRankLoss's term
+  // and its two gradients g+, g- for the row (pair_rank_loss_layer.cpp:28-37, 72-79), and writes what the backward
+  // needs -- da+ = g+ P_i, da- = g- P_i, B_i = g+ a+_i + g- a-_i -- so that neither P nor the (N, 1) score diffs ever
+  // reach HBM; trip_terms[i] = the row's loss term.  C must be null.
+  const float* Y2; const float* trip_y; float trip_margin, trip_s0, trip_s1; int trip_hinge_ge;
+  float* trip_sneg; float* trip_terms; float* trip_dapos; float* trip_daneg; float* trip_b;
 };
 
 constexpr int PG_LDA = 40;           // A_KC image row stride (32 k values + 8 pad floats)
@@ -476,6 +484,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int NC = p.N >> 2;                            // float4 per row of C
   constexpr int NCC = (4 * NT + 15) / 16;
   pg_v4f y4[4][NCC];                                  // loaders, row dot: Y rows g + 4 rr of this wave's block
+  pg_v4f y4b[4][NCC];                                 // ... and Y2's (fused triplet step)
   if (loader) {
     // A loader issues ~100 instructions per tile, its SIMD partner 250: at equal priority the younger loader
     // waited ~450 cycles per DMA for an issue slot (the loaders, not the matrix pipe, then paced the kernel)
@@ -488,6 +497,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int cc = 0; cc < NCC; ++cc) {
           const int c4 = r + 16 * cc;
           y4[rr][cc] = *reinterpret_cast<const pg_v4f*>(p.Y + (long long)growc * p.ldy + 4 * (c4 < NC ? c4 : 0));
+        }
+      }
+    }
+    if (p.Y2) {                                       // the negatives' rows, like Y
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int growc = min(i0 + g + 4 * rr, p.M - 1);
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) {
+          const int c4 = r + 16 * cc;
+          y4b[rr][cc] = *reinterpret_cast<const pg_v4f*>(p.Y2 + (long long)growc * p.ldy + 4 * (c4 < NC ? c4 : 0));
         }
       }
     }
@@ -661,6 +681,55 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // B_stage: the staged panel is visible to all 8 waves
 
+  if (p.Y2) {
+    // fused triplet step: the loader wave holds both answers' rows; it takes the two dots, PairRankLoss for the row
+    // and the three scaled row stores (the compute waves have nothing to add: P itself is not stored)
+    if (!loader) return;
+    float yv[4], diffv[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) yv[rr] = p.trip_y[min(i0 + g + 4 * rr, p.M - 1)];
+    asm volatile("" : "+v"(yv[0]), "+v"(yv[1]), "+v"(yv[2]), "+v"(yv[3]));
+    (void)diffv;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row_l = g + 4 * rr, grow = i0 + row_l;
+      const bool valid = grow < p.M;
+      pg_v4f v[NCC];
+      float dp = 0.f, dn = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < NCC; ++cc) {
+        const int c4 = r + 16 * cc;
+        if (c4 < NC) {
+          v[cc] = *reinterpret_cast<const pg_v4f*>(Cs + row_l * LD + 4 * c4);
+          dp += (v[cc][0] * y4[rr][cc][0] + v[cc][1] * y4[rr][cc][1]) + (v[cc][2] * y4[rr][cc][2] + v[cc][3] * y4[rr][cc][3]);
+          dn += (v[cc][0] * y4b[rr][cc][0] + v[cc][1] * y4b[rr][cc][1]) + (v[cc][2] * y4b[rr][cc][2] + v[cc][3] * y4b[rr][cc][3]);
+        }
+      }
+      dp = dpp_add<0xB1, 0xf>(dp); dn = dpp_add<0xB1, 0xf>(dn);      // every lane of the row's 16 ends with the totals
+      dp = dpp_add<0x4E, 0xf>(dp); dn = dpp_add<0x4E, 0xf>(dn);
+      dp = dpp_add<0x141, 0xf>(dp); dn = dpp_add<0x141, 0xf>(dn);
+      dp = dpp_add<0x140, 0xf>(dp); dn = dpp_add<0x140, 0xf>(dn);
+      const PairTerm pt = pair_term(dp, dn, yv[rr], p.trip_margin);   // pair_rank_loss_layer.cpp:28-37
+      float gp, gn;
+      pair_grad(yv[rr], pt.ordered, pt.similar, p.trip_s0, p.trip_s1, gp, gn, p.trip_hinge_ge != 0);   // :72-79
+      if (r == 0 && valid) {
+        p.rowdot[grow] = dp;
+        p.trip_sneg[grow] = dn;
+        p.trip_terms[grow] = pt.term;
+      }
+#pragma unroll
+      for (int cc = 0; cc < NCC; ++cc) {
+        const int c4 = r + 16 * cc;
+        if (c4 < NC && valid) {
+          const long long at = (long long)grow * p.ldy + 4 * c4;
+          __builtin_nontemporal_store(gp * v[cc], reinterpret_cast<pg_v4f*>(p.trip_dapos + at));     // da+ = g+ (W^T q)
+          __builtin_nontemporal_store(gn * v[cc], reinterpret_cast<pg_v4f*>(p.trip_daneg + at));     // da- = g- (W^T q)
+          *reinterpret_cast<pg_v4f*>(p.trip_b + at) = gp * y4[rr][cc] + gn * y4b[rr][cc];            // read next by two products
+        }
+      }
+    }
+    return;
+  }
   // Output pass over block `wave`'s 16 rows, lane (g, r): rows g + 4 rr, float4 r + 16 cc.  With a row dot the
   // loader wave (which holds Y) takes the dots and the compute wave the stores; otherwise they split the rows.
   float* Cg = p.C ? p.C + (long long)bt * p.c_b + (long long)ks * p.c_ks : nullptr;
@@ -745,6 +814,9 @@ inline bool panel_eligible(const PanelArgs& p, bool a_kc) {
   if (!a_kc && (!pg_mult4(p.M) || !p.kscale)) return false;
   if (p.C && (!pg_mult4(p.ldc) || !aligned16(p.C) || !pg_mult4(p.c_b) || !pg_mult4(p.c_ks))) return false;
   if (p.Y && (!pg_mult4(p.ldy) || !aligned16(p.Y))) return false;
+  if (p.Y2 && (!a_kc || !p.Y || p.C || p.ksplit != 1 || p.nb != 1 || p.nseg != 1 || !aligned16(p.Y2) || !p.trip_y || !p.rowdot ||
+               !p.trip_sneg || !p.trip_terms || !aligned16(p.trip_dapos) || !aligned16(p.trip_daneg) || !aligned16(p.trip_b)))
+    return false;
   if (p.ksplit > 1 && (p.nseg != 1 || (p.kchunk & 31))) return false;
   const int nt = p.N <= 64 ? 4 : p.N <= 112 ? 7 : p.N <= 208 ? 13 : 19;       // panel_launch's choice
   if (p.side_in && (p.ksplit != 1 || p.nb != 1 || !pg_mult4(p.side_cols) || p.side_cols > 16 * nt || !pg_mult4(p.side_ld) ||

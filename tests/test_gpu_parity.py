@@ -923,6 +923,61 @@ def test_triplet_workspaces_are_independent_and_recoverable(hiplib):
 
 
 # --------------------------------------------------------------------------- #
+# Fused learned-metric (q, a+, a-) step == SimMatrix x 2 -> PairRankLoss chain of the oracle
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("cfg", [(4096, 300, 300), (6145, 300, 300), (8192, 100, 200),   # the panel kernel's fast path
+                                 (333, 300, 300), (64, 7, 5), (2048, 302, 300)])          # the layers, one by one
+def test_triplet_simmatrix_step(cfg, oracle, hiplib):
+    """mms_triplet_simmatrix_step_f32 against the layer-by-layer chain (sim_matrix_layer.cpp:53-95 twice with W shared,
+    pair_rank_loss_layer.cpp:26-84, Split sum of dq): scores / loss / gradients at 1e-5, and -- given the GPU's own
+    scores -- PairRankLoss's per-row decisions bitwise: da_pos / da_neg must be EXACTLY g * (row of Q W) with the g the
+    oracle derives from those scores."""
+    from mms_answer_selection_amd import capi
+    N, K1, K2 = cfg
+    margin, lw = 0.3, 1.0
+    r = rng(N + K1 + 7 * K2)
+    q = (r.standard_normal((N, K1)) * 0.4).astype(np.float32)
+    ap = (r.standard_normal((N, K2)) * 0.4).astype(np.float32)
+    an = (r.standard_normal((N, K2)) * 0.4).astype(np.float32)
+    W = r.uniform(-0.08, 0.08, (K1, K2)).astype(np.float32)
+    y = (r.uniform(size=(N, 1)) < 0.8).astype(np.float32)
+    dW0 = r.standard_normal((K1, K2)).astype(np.float32)          # param diffs accumulate
+    sp, qw = oracle.simmatrix_forward(q, ap, W)
+    sn, _ = oracle.simmatrix_forward(q, an, W)
+    loss_ref, o, s = oracle.pairrank_forward(sp, sn, y, margin)
+    gsp, gsn = oracle.pairrank_backward(y, o, s, top_diff=lw)
+    dq_p, dap_ref, dW1 = oracle.simmatrix_backward(q, ap, W, gsp, dW_in=dW0.copy())
+    dq_n, dan_ref, dW_ref = oracle.simmatrix_backward(q, an, W, gsn, dW_in=dW1)
+    out = dict(s_pos=nan_like((N, 1)), s_neg=nan_like((N, 1)), loss=nan_like((1,)), dq=nan_like(q.shape),
+               da_pos=nan_like(ap.shape), da_neg=nan_like(an.shape), dW=dev(dW0))
+    capi.triplet_simmatrix_step(dev(q), dev(ap), dev(an), dev(y), dev(W), margin=margin, loss_weight=lw, **out)
+    g = {k: host(v) for k, v in out.items()}
+    assert_close(g["s_pos"], sp, TOL, "s_pos")
+    assert_close(g["s_neg"], sn, TOL, "s_neg")
+    assert_close(g["loss"][0], loss_ref, TOL, "loss")
+    # rows whose hinge argument sits within rounding of zero may decide differently from the oracle's scores: judge the
+    # gradients against the chain evaluated at the GPU's OWN scores (bit-exact PairRankLoss), and the products at 1e-5
+    loss2, o2, s2 = oracle.pairrank_forward(g["s_pos"], g["s_neg"], y, margin)
+    g2p, g2n = oracle.pairrank_backward(y, o2, s2, top_diff=lw)
+    assert_close(g["loss"][0], loss2, TOL, "loss at the GPU's scores")
+    dq2p, dap2, dW2a = oracle.simmatrix_backward(q, ap, W, g2p, dW_in=dW0.copy())
+    dq2n, dan2, dW2 = oracle.simmatrix_backward(q, an, W, g2n, dW_in=dW2a)
+    assert_close(g["da_pos"], dap2, TOL, "da_pos")
+    assert_close(g["da_neg"], dan2, TOL, "da_neg")
+    assert_close(g["dq"], dq2p + dq2n, TOL, "dq")
+    assert_close(g["dW"], dW2, 2e-5, "dW")
+    flips = int(((g2p != gsp) | (g2n != gsn)).sum())
+    assert flips <= max(2, N // 500), "%d rows decide the hinge differently from the oracle's scores" % flips
+    # a second call accumulates dW again and leaves everything else unchanged; loss = NULL is allowed
+    first = {k: v.clone() for k, v in out.items()}
+    out["loss"] = None
+    capi.triplet_simmatrix_step(dev(q), dev(ap), dev(an), dev(y), dev(W), margin=margin, loss_weight=lw, **out)
+    for k in ("s_pos", "s_neg", "dq", "da_pos", "da_neg"):
+        assert torch.equal(out[k], first[k]), k
+    assert_close(host(out["dW"]), 2 * dW2 - dW0, 4e-5, "dW accumulated twice")
+
+
+# --------------------------------------------------------------------------- #
 # Size-independent properties at full BASELINE sizes
 # --------------------------------------------------------------------------- #
 def test_properties_full_size(hiplib):
