@@ -1151,6 +1151,51 @@ def other_configs(torch, capi):
             "us_per_step": us, "pairs_per_s": N1 / (us * 1e-6), "TFLOPs": fl / us / 1e6,
             "frac_mfma_fp32_peak": fl / (us * 1e-6) / 157.3e12, "bound": "mfma / launch", "dtype": "f32"}
         del q1, a1, W1, b1, t1, dT1, dq1, da1, dW1, db1
+    # The real training step of the reference's network_v4 through the library's own layers (do_trec_qa_clean.py:452-470
+    # read as data): word ids (50, 40) x 2 -> Embed x 2 (one shared 50-d table, with bias) -> SimCross dist_mode 2,
+    # M = 4, bias -> backward -> Embed backward x 2 into the shared table's diff.  Batch 50, vocabulary 20,000.
+    Bt, Wd, Dv, Mv, Kv = 50, 40, 50, 4, 20000
+    tab = rnd(Kv, Dv)
+    ebias = torch.zeros(Dv, device="cuda")
+    iq = torch.randint(0, Kv, (Bt, Wd), device="cuda", generator=g).float()
+    ia = torch.randint(0, Kv, (Bt, Wd), device="cuda", generator=g).float()
+    iq[:, 30:] = Kv - 1                                                   # zero-pad id: sentences are shorter than 40 words
+    ia[:, 34:] = Kv - 1
+    qe, ae = torch.empty(Bt, Wd, Dv, device="cuda"), torch.empty(Bt, Wd, Dv, device="cuda")
+    Wv = torch.rand(Mv, Dv, Dv, device="cuda", generator=g) * 0.16 - 0.08
+    bv = torch.zeros(Mv, Wd, Wd, device="cuda")
+    tv = torch.empty(Bt, Mv, Wd, Wd, device="cuda")
+    dtv = torch.randn(Bt, Mv, Wd, Wd, device="cuda", generator=g)
+    dqe, dae = torch.empty_like(qe), torch.empty_like(ae)
+    dWv, dbv = torch.empty_like(Wv), torch.zeros_like(bv)
+    dtab, debias = torch.zeros_like(tab), torch.zeros_like(ebias)
+    wsv = capi.Workspace()
+
+    def v4_step():
+        capi.embed_forward(iq, tab, qe.view(-1, Dv), bias=ebias)
+        capi.embed_forward(ia, tab, ae.view(-1, Dv), bias=ebias)
+        capi.simcross_forward(2, qe, ae, tv, W=Wv, bias=bv, ws=wsv)
+        capi.simcross_backward(2, qe, ae, tv, dtv, dqe, dae, W=Wv, bias_term=True, dW=dWv, dbias=dbv, ws=wsv)
+        # Net::Backward runs the later layer (w2v_a) first; both into the one shared table diff, as ONE pass
+        capi.embed_backward_pair(ia, iq, dae.view(-1, Dv), dqe.view(-1, Dv), dtab, bias_diff=debias, ws=wsv)
+    us = _graph_time(torch, v4_step, iters=16)
+    parts = {}
+    for nm, fn in (("embed_forward_x2", lambda: (capi.embed_forward(iq, tab, qe.view(-1, Dv), bias=ebias),
+                                                 capi.embed_forward(ia, tab, ae.view(-1, Dv), bias=ebias))),
+                   ("simcross_forward", lambda: capi.simcross_forward(2, qe, ae, tv, W=Wv, bias=bv, ws=wsv)),
+                   ("simcross_backward", lambda: capi.simcross_backward(2, qe, ae, tv, dtv, dqe, dae, W=Wv, bias_term=True,
+                                                                        dW=dWv, dbias=dbv, ws=wsv)),
+                   ("embed_backward_x2_as_two_calls", lambda: (capi.embed_backward(ia, dae.view(-1, Dv), dtab, bias_diff=debias, ws=wsv),
+                                                               capi.embed_backward(iq, dqe.view(-1, Dv), dtab, bias_diff=debias, ws=wsv))),
+                   ("embed_backward_pair", lambda: capi.embed_backward_pair(ia, iq, dae.view(-1, Dv), dqe.view(-1, Dv), dtab,
+                                                                            bias_diff=debias, ws=wsv))):
+        parts[nm] = _graph_time(torch, fn, iters=16)
+    out["network_v4_training_step_batch50"] = {
+        "us_per_step": us, "pairs_per_s": Bt / (us * 1e-6), "parts_us": parts,
+        "note": "Embed x2 -> SimCross bilinear M=4 + bias -> backward -> both Embed backwards as one pass over the shared "
+                "table (mms_embed_backward_pair_f32), through the C ABI, graph-replayed; parts timed alone"}
+    del tab, iq, ia, qe, ae, Wv, bv, tv, dtv, dqe, dae, dWv, dbv, dtab
+
     # PairRankLoss alone (forward s*5*count bytes, backward s*5*count): the batch of cfg 2 and a
     # size at which bandwidth rather than the launch floor is visible
     for cnt in (N_PAIRS, 1 << 22):

@@ -435,6 +435,15 @@ int mms_embed_forward_f32(int M, int N, int K, const float* index, const float* 
 int mms_embed_backward_f32(int M, int N, int K, const float* index, const float* top_diff,
                            float* weight_diff, float* bias_diff, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* Two Embed layers that share ONE table (and bias) -- network_v4's w2v_q / w2v_a, do_trec_qa_clean.py:452-467 --
+ * back-propagated in one pass: exactly mms_embed_backward_f32(layer 0) followed by mms_embed_backward_f32(layer 1) into
+ * the same weight_diff / bias_diff (pass the layer whose Backward the net runs first -- the LATER layer of the file --
+ * as layer 0), with the same bits in weight_diff (a table row's additions keep the order "layer 0's rows ascending,
+ * then layer 1's"), but the inverted index is built once over M0 + M1 indices, every touched table row is read and
+ * written once, and the bias gradient is one column sum.  workspace: mms_embed_workspace_bytes(M0 + M1, N). */
+int mms_embed_backward_pair_f32(int M0, int M1, int N, int K, const float* index0, const float* top_diff0,
+                                const float* index1, const float* top_diff1, float* weight_diff, float* bias_diff,
+                                void* workspace, size_t workspace_bytes, void* stream);
 
 size_t mms_embed_workspace_bytes(int M, int N);
 

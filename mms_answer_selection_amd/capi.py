@@ -44,6 +44,7 @@ _SIGNATURES = {
     "mms_embed_workspace_bytes": (_sz, [_i, _i]),
     "mms_embed_forward_f32": (_i, [_i, _i, _i] + [_vp] * 5),
     "mms_embed_backward_f32": (_i, [_i, _i, _i] + [_vp] * 5 + [_sz, _vp]),
+    "mms_embed_backward_pair_f32": (_i, [_i, _i, _i, _i] + [_vp] * 6 + [_vp, _sz, _vp]),
     "mms_feed_gather_rows_f32": (_i, [_i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "mms_simcross_workspace_bytes_f64": (_sz, [_i] * 6),
     "mms_simcross_forward_f64": (_i, [_i] * 6 + [_vp] * 8 + [_sz, _vp]),
@@ -414,6 +415,16 @@ def embed_backward(index, top_diff, weight_diff, bias_diff=None, ws=None):
                                        _ptr(weight_diff, "weight_diff", True),
                                        _ptr(bias_diff, "bias_diff", True), wsp, wsb, _stream()),
           "mms_embed_backward_f32")
+
+
+def embed_backward_pair(index0, index1, top_diff0, top_diff1, weight_diff, bias_diff=None, ws=None):
+    """Backward of two Embed layers over one table in one pass: layer 0's rows, then layer 1's (include/mms.h)."""
+    M0, M1, (K, N) = index0.numel(), index1.numel(), weight_diff.shape
+    wsp, wsb = (ws or _default_ws).get(lib().mms_embed_workspace_bytes(M0 + M1, N), index0.device)
+    check(lib().mms_embed_backward_pair_f32(M0, M1, N, K, _ptr(index0, "index0"), _ptr(top_diff0, "top_diff0"),
+                                            _ptr(index1, "index1"), _ptr(top_diff1, "top_diff1"),
+                                            _ptr(weight_diff, "weight_diff", True), _ptr(bias_diff, "bias_diff", True),
+                                            wsp, wsb, _stream()), "mms_embed_backward_pair_f32")
 
 
 def feed_gather_rows(src, first, rows, dst, perm=None):

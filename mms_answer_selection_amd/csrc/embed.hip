@@ -23,6 +23,19 @@
 
 namespace mms {
 
+// The rows a backward pass adds, in order: layer 0's M0 rows, then (optionally) layer 1's -- the VIRTUAL concatenation
+// of two Embed layers that share one table (network_v4's w2v_q / w2v_a, do_trec_qa_clean.py:452-467), whose Backward
+// calls the reference runs one after the other into the same weight diff (embed_layer.cpp:155-180): row n of the
+// concatenation is layer 0's row n, or layer 1's row n - M0.  A single layer is M0 = M, second = null.
+struct EmbedSrc {
+  const float* index0; const float* diff0; int M0;
+  const float* index1; const float* diff1;
+  __device__ __forceinline__ float index(int n) const { return n < M0 ? index0[n] : index1[n - M0]; }
+  __device__ __forceinline__ const float* row(unsigned n, int N) const {
+    return (int)n < M0 ? diff0 + (size_t)n * N : diff1 + (size_t)(n - M0) * N;
+  }
+};
+
 __global__ __launch_bounds__(256) void embed_fwd_kernel(int M, int N, int K,
                                                         const float* __restrict__ index,
                                                         const float* __restrict__ weight,
@@ -42,12 +55,12 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(int M, int N, int K,
   }
 }
 
-__global__ __launch_bounds__(256) void embed_keys_kernel(int M, int K, const float* __restrict__ index,
+__global__ __launch_bounds__(256) void embed_keys_kernel(int M, int K, EmbedSrc src,
                                                          unsigned* __restrict__ keys,
                                                          unsigned* __restrict__ vals) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= M) return;
-  int idx = (int)index[n];
+  int idx = (int)src.index(n);
   idx = idx < 0 ? 0 : (idx >= K ? K - 1 : idx);
   keys[n] = (unsigned)idx;
   vals[n] = (unsigned)n;
@@ -72,7 +85,7 @@ template <int CH, int GW>   // GW gathering waves; block = 64 * (GW + 1) threads
 __global__ __launch_bounds__(64 * (GW + 1)) void embed_bwd_seg_kernel(
     int M, int N, const unsigned* __restrict__ keys, const unsigned* __restrict__ vals,
     const unsigned* __restrict__ heads, const unsigned* __restrict__ nseg,
-    const float* __restrict__ top_diff, float* __restrict__ weight_diff, int rmin, int rmax) {
+    EmbedSrc src, float* __restrict__ weight_diff, int rmin, int rmax) {
   extern __shared__ float seg_buf[];             // [2][CH][64] floats, then [2][CH] row numbers
   constexpr int RPT = CH / GW;                   // rows per gathering thread per chunk
   static_assert(CH % GW == 0, "chunk rows must divide evenly over the gathering waves");
@@ -93,7 +106,7 @@ __global__ __launch_bounds__(64 * (GW + 1)) void embed_bwd_seg_kernel(
     if (gt < 0) return;
     float x[RPT];
 #pragma unroll
-    for (int u = 0; u < RPT; ++u) x[u] = top_diff[(size_t)vbuf[b * CH + rg + u * GW] * N + gcol];
+    for (int u = 0; u < RPT; ++u) x[u] = src.row(vbuf[b * CH + rg + u * GW], N)[gcol];
 #pragma unroll
     for (int u = 0; u < RPT; ++u) seg_buf[(b * CH + rg + u * GW) * 64 + col] = x[u];
   };
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(64 * (GW + 1)) void embed_bwd_seg_kernel(
 // launches of the device-wide sort + select (each a few microseconds of pure latency).
 constexpr int kPrepThreads = 1024, kPrepItems = 4, kPrepMax = kPrepThreads * kPrepItems;
 __global__ __launch_bounds__(kPrepThreads) void embed_prep_small_kernel(
-    int M, int K, unsigned bits, const float* __restrict__ index, unsigned* __restrict__ keys,
+    int M, int K, unsigned bits, EmbedSrc src, unsigned* __restrict__ keys,
     unsigned* __restrict__ vals, unsigned* __restrict__ heads, unsigned* __restrict__ nseg) {
   using sort_t = rocprim::block_radix_sort<unsigned, kPrepThreads, kPrepItems, unsigned>;
   using scan_t = rocprim::block_scan<unsigned, kPrepThreads>;
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(kPrepThreads) void embed_prep_small_kernel(
 #pragma unroll
   for (int i = 0; i < kPrepItems; ++i) {
     const int n = t * kPrepItems + i;
-    int idx = n < M ? (int)index[n] : 0;
+    int idx = n < M ? (int)src.index(n) : 0;
     idx = idx < 0 ? 0 : (idx >= K ? K - 1 : idx);
     k[i] = n < M ? (unsigned)idx : 0xffffffffu;  // padding sorts to the end (all `bits` + the pad bit)
     v[i] = (unsigned)n;
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(kPrepThreads) void embed_prep_small_kernel(
 __global__ __launch_bounds__(256) void embed_bwd_short_kernel(
     int M, int N, const unsigned* __restrict__ keys, const unsigned* __restrict__ vals,
     const unsigned* __restrict__ heads, const unsigned* __restrict__ nseg,
-    const float* __restrict__ top_diff, float* __restrict__ weight_diff) {
+    EmbedSrc src, float* __restrict__ weight_diff) {
   const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int c = blockIdx.y * 64 + lane;
   const int count = (int)nseg[0];
@@ -193,30 +206,44 @@ __global__ __launch_bounds__(256) void embed_bwd_short_kernel(
   if (R <= 8) {
     float x[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) x[u] = top_diff[(size_t)vals[p + min(u, R - 1)] * N + gc];
+    for (int u = 0; u < 8; ++u) x[u] = src.row(vals[p + min(u, R - 1)], N)[gc];
 #pragma unroll
     for (int u = 0; u < 8; ++u) if (u < R) acc = 1.0f * x[u] + acc;
   } else {
     float x[32];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) x[u] = top_diff[(size_t)vals[p + min(u, R - 1)] * N + gc];
+    for (int u = 0; u < 32; ++u) x[u] = src.row(vals[p + min(u, R - 1)], N)[gc];
 #pragma unroll
     for (int u = 0; u < 32; ++u) if (u < R) acc = 1.0f * x[u] + acc;
   }
   if (c < N) weight_diff[(size_t)idx * N + c] = acc;
 }
 
-// bias_diff += column sums of top_diff (gemv in the reference: BLAS order, 1e-5 bar).
-constexpr int kBiasChunk = 512;
-__global__ __launch_bounds__(256) void embed_bias_partial_kernel(int M, int N,
-                                                                 const float* __restrict__ top_diff,
+// bias_diff += column sums of top_diff (caffe_cpu_gemv in the reference, embed_layer.cpp:176-178: BLAS order, 1e-5
+// bar).  Round 3: the first cut gave each of 50 threads a 512-row dependent load-add loop -- 104 us per Embed layer at
+// the driver's batch, 70 % of a whole training step of network_v4 (profiles/r03_v4_step_kernel_stats.csv).  Now a
+// workgroup owns 128 rows as 4 row lanes x 64 columns, eight independent loads in flight per thread, the four lanes
+// folded through LDS in a fixed order: 2,000 rows are 16 workgroups of ~32 loads per thread.
+constexpr int kBiasChunk = 128;
+__global__ __launch_bounds__(256) void embed_bias_partial_kernel(int M, int N, EmbedSrc src,
                                                                  float* __restrict__ partial) {
-  const int c = blockIdx.x;
+  __shared__ float red[4][64];
+  const int c = blockIdx.x, ry = threadIdx.x >> 6, dl = threadIdx.x & 63;
   const int n0 = c * kBiasChunk, n1 = min(M, n0 + kBiasChunk);
-  for (int d = threadIdx.x; d < N; d += 256) {
+  for (int d0 = 0; d0 < N; d0 += 64) {
+    const int d = min(d0 + dl, N - 1);
     float s = 0.f;
-    for (int n = n0; n < n1; ++n) s += top_diff[(size_t)n * N + d];
-    partial[(size_t)c * N + d] = s;
+    for (int nb = n0 + ry; nb < n1; nb += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src.row((unsigned)min(nb + 4 * u, M - 1), N)[d];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (nb + 4 * u < n1) ? v[u] : 0.f;
+    }
+    red[ry][dl] = s;
+    __syncthreads();
+    if (ry == 0 && d0 + dl < N) partial[(size_t)c * N + d0 + dl] = ((red[0][dl] + red[1][dl]) + red[2][dl]) + red[3][dl];
+    __syncthreads();
   }
 }
 __global__ __launch_bounds__(256) void embed_bias_finish_kernel(int chunks, int N,
@@ -258,8 +285,8 @@ int embed_forward(int M, int N, int K, const float* index, const float* weight, 
   return launch_status();
 }
 
-int embed_backward(int M, int N, int K, const float* index, const float* top_diff,
-                   float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes, hipStream_t s) {
+static int embed_backward_src(int M, int N, int K, const EmbedSrc& src,
+                              float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes, hipStream_t s) {
   const EmbedWs lay = embed_ws(M, N);
   if (!ws || ws_bytes < lay.temp) return MMS_ERR_WORKSPACE;
   char* base = static_cast<char*>(ws);
@@ -273,10 +300,10 @@ int embed_backward(int M, int N, int K, const float* index, const float* top_dif
     auto* heads = reinterpret_cast<unsigned*>(base + lay.heads);
     auto* nseg = reinterpret_cast<unsigned*>(base + lay.nseg);
     if (M <= kPrepMax && bits < 32) {
-      hipLaunchKernelGGL(embed_prep_small_kernel, dim3(1), dim3(kPrepThreads), 0, s, M, K, bits, index, k1, v1,
+      hipLaunchKernelGGL(embed_prep_small_kernel, dim3(1), dim3(kPrepThreads), 0, s, M, K, bits, src, k1, v1,
                          heads, nseg);
     } else {
-      hipLaunchKernelGGL(embed_keys_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, K, index,
+      hipLaunchKernelGGL(embed_keys_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, K, src,
                          k0, v0);
       size_t need = 0;
       if (rocprim::radix_sort_pairs(nullptr, need, k0, k1, v0, v1, (size_t)M, 0u, bits, s) != hipSuccess)
@@ -301,18 +328,34 @@ int embed_backward(int M, int N, int K, const float* index, const float* top_dif
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLongLds);
     (void)once;
     hipLaunchKernelGGL(embed_bwd_short_kernel, dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, s, M, N, k1, v1,
-                       heads, nseg, top_diff, weight_diff);
+                       heads, nseg, src, weight_diff);
     hipLaunchKernelGGL((embed_bwd_seg_kernel<256, 8>), grid, dim3(576), kLongLds, s, M, N, k1, v1, heads, nseg,
-                       top_diff, weight_diff, 33, 0x7fffffff);
+                       src, weight_diff, 33, 0x7fffffff);
   }
   if (bias_diff) {
     float* partial = reinterpret_cast<float*>(base + lay.partial);
     hipLaunchKernelGGL(embed_bias_partial_kernel, dim3((unsigned)lay.chunks), dim3(256), 0, s, M, N,
-                       top_diff, partial);
+                       src, partial);
     hipLaunchKernelGGL(embed_bias_finish_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s,
                        lay.chunks, N, partial, bias_diff);
   }
   return launch_status();
+}
+
+int embed_backward(int M, int N, int K, const float* index, const float* top_diff,
+                   float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes, hipStream_t s) {
+  const EmbedSrc src{index, top_diff, M, nullptr, nullptr};
+  return embed_backward_src(M, N, K, src, weight_diff, bias_diff, ws, ws_bytes, s);
+}
+
+// Two Embed layers over ONE table: layer 0's Backward, then layer 1's, as one pass over the concatenation of their
+// rows (the inverted index is built once, every table row is read and written once, the bias gradient is one sum).
+// Same bits as the two calls: a table row's additions keep the order "layer 0's rows ascending, then layer 1's".
+int embed_backward_pair(int M0, int M1, int N, int K, const float* index0, const float* top_diff0, const float* index1,
+                        const float* top_diff1, float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes,
+                        hipStream_t s) {
+  const EmbedSrc src{index0, top_diff0, M0, index1, top_diff1};
+  return embed_backward_src(M0 + M1, N, K, src, weight_diff, bias_diff, ws, ws_bytes, s);
 }
 
 // ---- batch feed: rows of a device-resident dataset -> one top blob -----------------

@@ -69,6 +69,9 @@ int embed_forward(int M, int N, int K, const float* index, const float* weight, 
                   float* top, hipStream_t s);
 int embed_backward(int M, int N, int K, const float* index, const float* top_diff,
                    float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes, hipStream_t s);
+int embed_backward_pair(int M0, int M1, int N, int K, const float* index0, const float* top_diff0, const float* index1,
+                        const float* top_diff1, float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes,
+                        hipStream_t s);
 int euclid_backward_mode();
 void set_euclid_backward_mode(int m);
 int pairrank_hinge_mode();
@@ -471,6 +474,16 @@ int mms_rank_accuracy_f32(int count, const float* a, const float* b, const float
   if (count <= 0) return MMS_ERR_INVALID_ARG;
   if (!a || !b || !label || !acc_out) return MMS_ERR_INVALID_ARG;
   return rank_accuracy(count, a, b, label, acc_out, workspace, workspace_bytes, as_stream(stream));
+}
+
+int mms_embed_backward_pair_f32(int M0, int M1, int N, int K, const float* index0, const float* top_diff0,
+                                const float* index1, const float* top_diff1, float* weight_diff, float* bias_diff,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (M0 <= 0 || M1 <= 0 || N <= 0 || K <= 0 || !index0 || !top_diff0 || !index1 || !top_diff1) return MMS_ERR_INVALID_ARG;
+  if ((long long)M0 + M1 > 0x7fffffffLL || ((long long)M0 + M1) * N > 0x7fffffffLL) return MMS_ERR_INVALID_ARG;
+  if (!weight_diff && !bias_diff) return MMS_OK;
+  return embed_backward_pair(M0, M1, N, K, index0, top_diff0, index1, top_diff1, weight_diff, bias_diff, workspace,
+                             workspace_bytes, as_stream(stream));
 }
 
 size_t mms_embed_workspace_bytes(int M, int N) { return (M > 0 && N > 0) ? embed_workspace_bytes(M, N) : 0; }

@@ -45,6 +45,37 @@ def test_embed_forward_backward(cfg, oracle, hiplib):
     assert_bitexact(wd2.cpu().numpy(), wd_ref)
 
 
+@pytest.mark.parametrize("cfg", [(2000, 2000, 50, 20000), (2000, 1360, 50, 300), (3, 5, 7, 4), (6000, 7000, 50, 2000),
+                                 (1, 1, 300, 1)])
+def test_embed_backward_pair_is_the_two_backwards(cfg, oracle, hiplib):
+    """mms_embed_backward_pair_f32: two Embed layers over one table in one pass == layer 0's Backward then layer 1's
+    (embed_layer.cpp:155-180 twice into the same diffs): weight_diff bit for bit, bias_diff at 1e-5 (gemv)."""
+    from mms_answer_selection_amd import capi
+    M0, M1, N, K = cfg
+    r = rng(M0 + 3 * M1 + N)
+    idx = []
+    for M in (M0, M1):
+        i = r.integers(0, K, M)
+        i[r.uniform(size=M) < 0.3] = K - 1              # zero-pad id: a long segment that spans both layers
+        idx.append(i.astype(np.float32))
+    d0 = r.standard_normal((M0, N)).astype(np.float32)
+    d1 = r.standard_normal((M1, N)).astype(np.float32)
+    wd0 = r.standard_normal((K, N)).astype(np.float32)
+    bd0 = r.standard_normal(N).astype(np.float32)
+    wd_a, bd_a = oracle.embed_backward(idx[0], d0, wd0, bd0)
+    wd_ref, bd_ref = oracle.embed_backward(idx[1], d1, wd_a, bd_a)
+    wd, bd = dev(wd0), dev(bd0)
+    capi.embed_backward_pair(dev(idx[0]), dev(idx[1]), dev(d0), dev(d1), wd, bias_diff=bd)
+    assert_bitexact(wd.cpu().numpy(), wd_ref, "weight_diff: layer 0's rows ascending, then layer 1's")
+    assert_close(bd.cpu().numpy(), bd_ref, TOL, "bias_diff")
+    # ... and equals the two single-layer calls of this library bit for bit
+    wd2, bd2 = dev(wd0), dev(bd0)
+    capi.embed_backward(dev(idx[0]), dev(d0), wd2, bd2)
+    capi.embed_backward(dev(idx[1]), dev(d1), wd2, bd2)
+    assert_bitexact(wd.cpu().numpy(), wd2.cpu().numpy(), "pair == two calls")
+    assert_close(bd.cpu().numpy(), bd2.cpu().numpy(), TOL, "bias_diff pair vs two calls")
+
+
 @pytest.mark.parametrize("cfg", [(1517, 40, 40, 50, 20000), (1100, 16, 24, 50, 300), (7, 40, 40, 50, 100),
                                  (5, 9, 13, 33, 40), (3, 40, 40, 300, 500), (600, 1, 1, 20, 64)])
 def test_embed_fused_into_simcross_forward(cfg, oracle, hiplib):

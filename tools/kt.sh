@@ -2,7 +2,7 @@
 # tools/kt.sh TAG CMD... -- dev-only, ON THE GPU BOX: rocprofv3 --kernel-trace --stats of CMD, prints the kernel stats table.
 set -o pipefail
 TAG=$1; shift
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/r2/kt_$TAG; mkdir -p $OUT
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/r3/kt_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- "$@" > $OUT/run.out 2> $OUT/run.err || { tail -5 $OUT/run.err; exit 1; }
 cd $ROOT
