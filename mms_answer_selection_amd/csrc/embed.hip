@@ -138,6 +138,64 @@ __global__ __launch_bounds__(64 * (GW + 1)) void embed_bwd_seg_kernel(
   if (adder) weight_diff[(size_t)idx * N + c0 + tid] = acc;
 }
 
+// bias_diff += column sums of top_diff (caffe_cpu_gemv in the reference, embed_layer.cpp:176-178: BLAS order, 1e-5
+// bar).  Round 3: the first cut gave each of 50 threads a 512-row dependent load-add loop -- 104 us per Embed layer at
+// the driver's batch, 70 % of a whole training step of network_v4 (profiles/r03_v4_step_kernel_stats.csv).  Now a
+// workgroup owns 128 rows as LANES row lanes x 64 columns, eight independent loads in flight per thread, the lanes
+// folded through LDS in a fixed order.  For small batches the two launches ride along with launches that leave the
+// chip idle anyway: the partial sums in the workgroups NEXT to the one-workgroup inverted-index build, the final sum
+// in workgroups appended to the short-segment launch (3 launches per backward pass instead of 5).
+constexpr int kBiasChunk = 128;
+template <int LANES>                                  // blockDim.x == 64 * LANES
+__device__ __forceinline__ void embed_bias_partial_body(int c, int M, int N, const EmbedSrc& src,
+                                                        float* __restrict__ partial, float (*red)[64]) {
+  const int ry = threadIdx.x >> 6, dl = threadIdx.x & 63;
+  const int n0 = c * kBiasChunk, n1 = min(M, n0 + kBiasChunk);
+  for (int d0 = 0; d0 < N; d0 += 64) {
+    const int d = min(d0 + dl, N - 1);
+    float s = 0.f;
+    for (int nb = n0 + ry; nb < n1; nb += 8 * LANES) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src.row((unsigned)min(nb + LANES * u, M - 1), N)[d];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (nb + LANES * u < n1) ? v[u] : 0.f;
+    }
+    red[ry][dl] = s;
+    __syncthreads();
+    if (ry == 0 && d0 + dl < N) {
+      float t = red[0][dl];
+#pragma unroll
+      for (int l = 1; l < LANES; ++l) t += red[l][dl];
+      partial[(size_t)c * N + d0 + dl] = t;
+    }
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ void embed_bias_finish_body(int d, int chunks, int N, const float* __restrict__ partial,
+                                                       float* __restrict__ bias_diff) {
+  if (d >= N) return;
+  float s = 0.f;
+  for (int c0 = 0; c0 < chunks; c0 += 8) {       // eight loads in flight, same c-ascending order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)min(c0 + u, chunks - 1) * N + d];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (c0 + u < chunks) ? v[u] : 0.f;
+  }
+  bias_diff[d] = 1.0f * s + 1.0f * bias_diff[d];
+}
+__global__ __launch_bounds__(256) void embed_bias_partial_kernel(int M, int N, EmbedSrc src,
+                                                                 float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  embed_bias_partial_body<4>((int)blockIdx.x, M, N, src, partial, red);
+}
+__global__ __launch_bounds__(256) void embed_bias_finish_kernel(int chunks, int N,
+                                                                const float* __restrict__ partial,
+                                                                float* __restrict__ bias_diff) {
+  embed_bias_finish_body((int)(blockIdx.x * 256 + threadIdx.x), chunks, N, partial, bias_diff);
+}
+
 // Small batches (M <= 4096: the driver's 50 x 40-word training batch is 2,000 indices per Embed
 // layer): the whole inverted index -- clamp, stable radix sort of (id, n), head flags, compaction
 // of the head positions and their count -- in ONE workgroup and one launch instead of the dozen
@@ -145,7 +203,13 @@ __global__ __launch_bounds__(64 * (GW + 1)) void embed_bwd_seg_kernel(
 constexpr int kPrepThreads = 1024, kPrepItems = 4, kPrepMax = kPrepThreads * kPrepItems;
 __global__ __launch_bounds__(kPrepThreads) void embed_prep_small_kernel(
     int M, int K, unsigned bits, EmbedSrc src, unsigned* __restrict__ keys,
-    unsigned* __restrict__ vals, unsigned* __restrict__ heads, unsigned* __restrict__ nseg) {
+    unsigned* __restrict__ vals, unsigned* __restrict__ heads, unsigned* __restrict__ nseg,
+    int N, float* __restrict__ bias_partial) {
+  if (blockIdx.x > 0) {                          // riders: the bias gradient's partial sums (bias_partial != null)
+    __shared__ float red[kPrepThreads / 64][64];
+    embed_bias_partial_body<kPrepThreads / 64>((int)blockIdx.x - 1, M, N, src, bias_partial, red);
+    return;
+  }
   using sort_t = rocprim::block_radix_sort<unsigned, kPrepThreads, kPrepItems, unsigned>;
   using scan_t = rocprim::block_scan<unsigned, kPrepThreads>;
   __shared__ union { typename sort_t::storage_type sort; typename scan_t::storage_type scan; } tmp;
@@ -192,7 +256,13 @@ __global__ __launch_bounds__(kPrepThreads) void embed_prep_small_kernel(
 __global__ __launch_bounds__(256) void embed_bwd_short_kernel(
     int M, int N, const unsigned* __restrict__ keys, const unsigned* __restrict__ vals,
     const unsigned* __restrict__ heads, const unsigned* __restrict__ nseg,
-    EmbedSrc src, float* __restrict__ weight_diff) {
+    EmbedSrc src, float* __restrict__ weight_diff, int seg_blocks, int bias_chunks,
+    const float* __restrict__ bias_partial, float* __restrict__ bias_diff) {
+  if ((int)blockIdx.x >= seg_blocks) {           // riders: the bias gradient's final sum (the partials are a launch old)
+    if (blockIdx.y == 0)
+      embed_bias_finish_body(((int)blockIdx.x - seg_blocks) * 256 + (int)threadIdx.x, bias_chunks, N, bias_partial, bias_diff);
+    return;
+  }
   const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int c = blockIdx.y * 64 + lane;
   const int count = (int)nseg[0];
@@ -217,49 +287,6 @@ __global__ __launch_bounds__(256) void embed_bwd_short_kernel(
     for (int u = 0; u < 32; ++u) if (u < R) acc = 1.0f * x[u] + acc;
   }
   if (c < N) weight_diff[(size_t)idx * N + c] = acc;
-}
-
-// bias_diff += column sums of top_diff (caffe_cpu_gemv in the reference, embed_layer.cpp:176-178: BLAS order, 1e-5
-// bar).  Round 3: the first cut gave each of 50 threads a 512-row dependent load-add loop -- 104 us per Embed layer at
-// the driver's batch, 70 % of a whole training step of network_v4 (profiles/r03_v4_step_kernel_stats.csv).  Now a
-// workgroup owns 128 rows as 4 row lanes x 64 columns, eight independent loads in flight per thread, the four lanes
-// folded through LDS in a fixed order: 2,000 rows are 16 workgroups of ~32 loads per thread.
-constexpr int kBiasChunk = 128;
-__global__ __launch_bounds__(256) void embed_bias_partial_kernel(int M, int N, EmbedSrc src,
-                                                                 float* __restrict__ partial) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x, ry = threadIdx.x >> 6, dl = threadIdx.x & 63;
-  const int n0 = c * kBiasChunk, n1 = min(M, n0 + kBiasChunk);
-  for (int d0 = 0; d0 < N; d0 += 64) {
-    const int d = min(d0 + dl, N - 1);
-    float s = 0.f;
-    for (int nb = n0 + ry; nb < n1; nb += 32) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src.row((unsigned)min(nb + 4 * u, M - 1), N)[d];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += (nb + 4 * u < n1) ? v[u] : 0.f;
-    }
-    red[ry][dl] = s;
-    __syncthreads();
-    if (ry == 0 && d0 + dl < N) partial[(size_t)c * N + d0 + dl] = ((red[0][dl] + red[1][dl]) + red[2][dl]) + red[3][dl];
-    __syncthreads();
-  }
-}
-__global__ __launch_bounds__(256) void embed_bias_finish_kernel(int chunks, int N,
-                                                                const float* __restrict__ partial,
-                                                                float* __restrict__ bias_diff) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= N) return;
-  float s = 0.f;
-  for (int c0 = 0; c0 < chunks; c0 += 8) {       // eight loads in flight, same c-ascending order
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)min(c0 + u, chunks - 1) * N + d];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += (c0 + u < chunks) ? v[u] : 0.f;
-  }
-  bias_diff[d] = 1.0f * s + 1.0f * bias_diff[d];
 }
 
 struct EmbedWs { size_t k0, k1, v0, v1, flags, heads, nseg, partial, temp, total; int chunks; };
@@ -294,14 +321,16 @@ static int embed_backward_src(int M, int N, int K, const EmbedSrc& src,
   auto* k1 = reinterpret_cast<unsigned*>(base + lay.k1);
   auto* v0 = reinterpret_cast<unsigned*>(base + lay.v0);
   auto* v1 = reinterpret_cast<unsigned*>(base + lay.v1);
+  bool bias_rides = false;                          // the bias gradient rode along with the weight gradient's launches
   if (weight_diff) {
     unsigned bits = 1;                              // keys are clamped to [0, K): sort those bits only
     while (bits < 32 && (1ull << bits) < (unsigned long long)K) ++bits;
     auto* heads = reinterpret_cast<unsigned*>(base + lay.heads);
     auto* nseg = reinterpret_cast<unsigned*>(base + lay.nseg);
     if (M <= kPrepMax && bits < 32) {
-      hipLaunchKernelGGL(embed_prep_small_kernel, dim3(1), dim3(kPrepThreads), 0, s, M, K, bits, src, k1, v1,
-                         heads, nseg);
+      bias_rides = bias_diff != nullptr;
+      hipLaunchKernelGGL(embed_prep_small_kernel, dim3(1u + (bias_rides ? (unsigned)lay.chunks : 0u)), dim3(kPrepThreads), 0,
+                         s, M, K, bits, src, k1, v1, heads, nseg, N, reinterpret_cast<float*>(base + lay.partial));
     } else {
       hipLaunchKernelGGL(embed_keys_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, K, src,
                          k0, v0);
@@ -327,12 +356,14 @@ static int embed_backward_src(int M, int N, int K, const EmbedSrc& src,
         reinterpret_cast<const void*>(&embed_bwd_seg_kernel<256, 8>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLongLds);
     (void)once;
-    hipLaunchKernelGGL(embed_bwd_short_kernel, dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, s, M, N, k1, v1,
-                       heads, nseg, src, weight_diff);
+    const unsigned seg_blocks = (grid.x + 3) / 4, fin_blocks = bias_rides ? (unsigned)((N + 255) / 256) : 0u;
+    hipLaunchKernelGGL(embed_bwd_short_kernel, dim3(seg_blocks + fin_blocks, grid.y), dim3(256), 0, s, M, N, k1, v1,
+                       heads, nseg, src, weight_diff, (int)seg_blocks, lay.chunks,
+                       reinterpret_cast<const float*>(base + lay.partial), bias_diff);
     hipLaunchKernelGGL((embed_bwd_seg_kernel<256, 8>), grid, dim3(576), kLongLds, s, M, N, k1, v1, heads, nseg,
                        src, weight_diff, 33, 0x7fffffff);
   }
-  if (bias_diff) {
+  if (bias_diff && !bias_rides) {
     float* partial = reinterpret_cast<float*>(base + lay.partial);
     hipLaunchKernelGGL(embed_bias_partial_kernel, dim3((unsigned)lay.chunks), dim3(256), 0, s, M, N,
                        src, partial);

@@ -370,6 +370,227 @@ __global__ __launch_bounds__(1024) void rank_small_kernel(int n, int stride, int
   }
 }
 
+// ---- 512 < n <= 2048 (round 3): the same one-workgroup metric with a sort that stays in registers -------------------
+// The LDS bitonic sort above pays a workgroup barrier and two LDS round trips for each of its log^2 passes: at 2,048
+// padded items that is 66 passes and 47 us, no better than rocPRIM's launches -- while 1,517 candidates are exactly
+// the TREC-QA test split a TEST net ranks per pass (cfg 4).  Here thread t of 1,024 holds items 2t and 2t + 1 in
+// registers; a compare-exchange at distance 1 is inside the thread, at distances 2..64 a wave shuffle (no barrier, no
+// LDS allocation), and only distances 128..1024 -- 10 of the 66 passes -- go through LDS with one barrier each
+// (ping-pong buffers).  Then the sorted (key, index) pairs are written to LDS once and the SAME bucket walks and the
+// SAME one-wave fold run on them: same expressions, same order, same bits.
+constexpr int kRankMid = 2048;
+template <int MODE>                                  // 0: MAP / MRR, 1: AUC
+__global__ __launch_bounds__(1024) void rank_mid_kernel(int n, int stride, int offset, int inner,
+                                                        const float* __restrict__ prob,
+                                                        const float* __restrict__ label,
+                                                        const float* __restrict__ group, int has_ignore,
+                                                        int ignore_label, float* __restrict__ out0,
+                                                        float* __restrict__ out1, int* __restrict__ effective) {
+  __shared__ unsigned long long keys[kRankMid];
+  __shared__ unsigned vals[kRankMid];
+  __shared__ unsigned long long xk[kRankMid];          // the second exchange buffer (cross-wave passes)
+  __shared__ unsigned xv[kRankMid];
+  __shared__ float ap[MODE == 0 ? kRankMid : 1];
+  __shared__ int rk[MODE == 0 ? kRankMid : 1];
+  __shared__ int fl[MODE == 0 ? kRankMid : 1];
+  __shared__ float slab[MODE == 0 ? kRankMid : 1];
+  const int t = threadIdx.x;
+#ifdef MMS_RANK_STAMPS      // dev-only (tools/rank_mid_probe.py): phase times in 10-ns ticks behind the results, out0[4..]
+  unsigned long long st0 = __builtin_amdgcn_s_memrealtime(), st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+#endif
+  unsigned long long k[2];
+  unsigned v[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = 2 * t + e;
+    k[e] = i < n ? rank_key(i, stride, offset, inner, prob, group) : ~0ull;   // padding sorts behind everything
+    v[e] = (unsigned)i;
+  }
+  // (key, index) in lexicographic order; `lower`: this element sits at the smaller position of its pair
+  auto keep_mine = [](unsigned long long km, unsigned vm, unsigned long long ko, unsigned vo, bool lower, bool up) {
+    const bool mine_gt = km > ko || (km == ko && vm > vo);
+    return (mine_gt == (lower == up)) ? false : true;   // ascending pair keeps the smaller one at the lower position
+  };
+#ifdef MMS_RANK_STAMPS
+  st1 = __builtin_amdgcn_s_memrealtime();
+#endif
+  int buf = 0;
+  for (int kk = 2; kk <= kRankMid; kk <<= 1) {
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      if (j == 1) {                                   // positions 2t and 2t + 1: inside the thread
+        const bool up = ((2 * t) & kk) == 0;
+        const bool gt = k[0] > k[1] || (k[0] == k[1] && v[0] > v[1]);
+        if (gt == up) {
+          const unsigned long long tk = k[0]; k[0] = k[1]; k[1] = tk;
+          const unsigned tv = v[0]; v[0] = v[1]; v[1] = tv;
+        }
+      } else if (j <= 64) {                           // partner thread t ^ (j / 2), same wave: shuffles
+        const int m = j >> 1;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int p = 2 * t + e;
+          const unsigned lo = __shfl_xor((unsigned)k[e], m, 64), hi = __shfl_xor((unsigned)(k[e] >> 32), m, 64);
+          const unsigned vo = __shfl_xor(v[e], m, 64);
+          const unsigned long long ko = ((unsigned long long)hi << 32) | lo;
+          const bool lower = (p & j) == 0, up = (p & kk) == 0;
+          if (!keep_mine(k[e], v[e], ko, vo, lower, up)) { k[e] = ko; v[e] = vo; }
+        }
+      } else {                                        // another wave: through LDS, one barrier per pass
+        unsigned long long* bk = buf ? xk : keys;
+        unsigned* bv = buf ? xv : vals;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { bk[2 * t + e] = k[e]; bv[2 * t + e] = v[e]; }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int p = 2 * t + e, q = p ^ j;
+          const unsigned long long ko = bk[q];
+          const unsigned vo = bv[q];
+          const bool lower = (p & j) == 0, up = (p & kk) == 0;
+          if (!keep_mine(k[e], v[e], ko, vo, lower, up)) { k[e] = ko; v[e] = vo; }
+        }
+        buf ^= 1;                                     // the next LDS pass writes the other buffer: this one may still be read
+      }
+    }
+  }
+  __syncthreads();                                    // the last readers of `keys` / `vals` as exchange buffers are done
+#ifdef MMS_RANK_STAMPS
+  st2 = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+  for (int e = 0; e < 2; ++e) { keys[2 * t + e] = k[e]; vals[2 * t + e] = v[e]; }
+  __syncthreads();
+  if (MODE == 0) {
+    // A lone workgroup runs at a fraction of the chip's loaded clock: the per-bucket walks of rank_bucket_at (one
+    // thread per bucket, a data-dependent exit and a division per item: two LDS round trips + ~40 dependent
+    // instructions per iteration) took 15.8 us at 1,517 items and the one-wave fold with its double divisions 7.6 us
+    // (stamps, tools/rank_mid_probe.py).  Same expressions and the same summation orders, but everything that is not
+    // a running fp sum now happens in parallel: bucket heads, lengths and positive counts by workgroup scans, every
+    // positive's term map_rank / (pos + 1) and every bucket's ap / map_rank and 1.0 / (mrr_rank + 1) by its own
+    // thread; what is left sequential is adds over loads whose addresses are known up front.
+    int* hd = rk;                                    // compacted bucket heads, hd[B] = n  (rk / fl / ap are free until the end)
+    float* term = ap;
+    __shared__ int wtot[2][16];
+    __shared__ int nb_s;
+    const int i0 = 2 * t, i1 = 2 * t + 1, lane = t & 63, wv = t >> 6;
+    // labels in sorted order (the gather through the permutation: global loads, all independent)
+    const int l0 = i0 < n ? (int)label[vals[i0]] : 0, l1 = i1 < n ? (int)label[vals[i1]] : 0;
+    const unsigned g0 = (unsigned)(k[0] >> 32), g1 = (unsigned)(k[1] >> 32);
+    const unsigned gprev = __shfl_up(g1, 1, 64);
+    unsigned gp = gprev;                             // group of position i0 - 1: the previous thread's second item
+    if (lane == 0) gp = t ? (unsigned)(keys[i0 - 1] >> 32) : 0u;
+    const int h0 = i0 < n && (i0 == 0 || gp != g0), h1 = i1 < n && g1 != g0;
+    // two workgroup scans at once over the items in position order: (a) bucket number = inclusive count of heads,
+    // (b) inclusive count of label == 1
+    int a0 = h0, a1 = h0 + h1, b0 = (l0 == 1), b1 = b0 + (l1 == 1);
+    int sa = a1, sb = b1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int oa = __shfl_up(sa, d, 64), ob = __shfl_up(sb, d, 64);
+      if (lane >= d) { sa += oa; sb += ob; }
+    }
+    if (lane == 63) { wtot[0][wv] = sa; wtot[1][wv] = sb; }
+    __syncthreads();
+    int pa = sa - a1, pb = sb - b1;                  // exclusive prefix inside the wave
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { if (w < wv) { pa += wtot[0][w]; pb += wtot[1][w]; } }
+    a0 += pa; a1 += pa; b0 += pb; b1 += pb;          // inclusive counts at positions i0, i1
+    if (t == 1023) nb_s = a1;                        // (padding positions add nothing)
+    slab[i0] = __int_as_float(l0); slab[i1] = __int_as_float(l1);     // labels as ints, position order
+    xv[i0] = (unsigned)b0; xv[i1] = (unsigned)b1;                       // positive counts (the exchange buffer is free)
+    if (h0) hd[a0 - 1] = i0;
+    if (h1) hd[a1 - 1] = i1;
+    __syncthreads();
+    const int B = nb_s;
+    if (t == 0) hd[B] = n;
+    __syncthreads();
+    // every positive's term, in parallel: (++map_rank) / (float)(pos + 1), map_layer.cpp:84-86
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int i = e ? i1 : i0;
+      if (i < n) {
+        const int bkt = (e ? a1 : a0) - 1, head = hd[bkt];
+        const int before = head ? (int)xv[head - 1] : 0;               // positives in front of the bucket
+        const int lab = e ? l1 : l0, mr = (int)(e ? b1 : b0) - before;
+        term[i] = lab == 1 ? mr / (float)(i - head + 1) : 0.f;
+      }
+    }
+    __syncthreads();
+    // one thread per bucket: the ordered sum of its terms (x + 0.0f == x: the non-positive items add nothing), its
+    // flags and its two quotients.  The bucket's extent is known, so the loads run ahead of the adds.
+    float b_ap = 0.f;
+    double b_inv = 0.0;
+    int b_fl = 0;
+    if (t < B) {
+      const int head = hd[t], end = hd[t + 1];
+      float apv = 0.f;
+      int not_one = 0, zero = 0, first = -1;
+      for (int p = head; p < end; p += 8) {
+        float tv[8];
+        int lv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int q = p + u < end ? p + u : end - 1; tv[u] = term[q]; lv[u] = __float_as_int(slab[q]); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (p + u < end) {
+            apv += tv[u];
+            if (lv[u] == 1) { if (first < 0) first = p + u - head; }
+            else { not_one = 1; if (lv[u] == 0) zero = 1; }
+          }
+        }
+      }
+      const int map_rank = (int)xv[end - 1] - (head ? (int)xv[head - 1] : 0);
+      if (map_rank >= 1 && not_one) { b_fl |= 1; b_ap = apv / map_rank; }                 // map_layer.cpp:92-94
+      if (first >= 0 && zero) { b_fl |= 2; b_inv = 1.0 / (first + 1); }                   // mrr_layer.cpp:75
+    }
+#ifdef MMS_RANK_STAMPS
+    st3 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // the fold over the buckets in sorted (ascending group) order: running sums only, one wave, 64 buckets per step
+    float* bap = reinterpret_cast<float*>(keys);     // (the sorted keys are not needed any more)
+    double* binv = reinterpret_cast<double*>(xk);
+    int* bfl = fl;
+    if (t < B) { bap[t] = b_ap; binv[t] = b_inv; bfl[t] = b_fl; }
+    __syncthreads();
+    if (t < 64) {
+      float map_ = 0.f, mrr = 0.f;
+      int eff_map = 0, eff_mrr = 0;
+      for (int base = 0; base < B; base += 64) {
+        const int bi = base + lane < B ? base + lane : B - 1;
+        const float la = bap[bi];
+        const long long li = __double_as_longlong(binv[bi]);
+        const int lf = base + lane < B ? bfl[bi] : 0;
+        unsigned long long m1 = __ballot(lf & 1), m2 = __ballot(lf & 2);
+        eff_map += __popcll(m1);
+        eff_mrr += __popcll(m2);
+        while (m1) {                                                   // map_layer.cpp:93-94
+          const int l = __ffsll((long long)m1) - 1;
+          m1 &= m1 - 1;
+          map_ += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(la), l));
+        }
+        while (m2) {   // mrr += 1.0/(mrr_rank+1): float + double, stored back to float (mrr_layer.cpp:75)
+          const int l = __ffsll((long long)m2) - 1;
+          m2 &= m2 - 1;
+          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(li & 0xffffffffll), l);
+          const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(li >> 32), l);
+          mrr = (float)((double)mrr + __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)));
+        }
+      }
+      if (lane == 0) {
+        if (out0) *out0 = map_ / eff_map;             // NaN when no bucket counts, like the reference (:99)
+        if (out1) *out1 = mrr / eff_mrr;
+        if (effective) *effective = eff_map;
+#ifdef MMS_RANK_STAMPS
+        st4 = __builtin_amdgcn_s_memrealtime();
+        out0[4] = (float)(st1 - st0); out0[5] = (float)(st2 - st1); out0[6] = (float)(st3 - st2); out0[7] = (float)(st4 - st3);
+#endif
+      }
+    }
+  } else {
+    if (t < 64) auc_fold_wave(t, n, vals, label, has_ignore, ignore_label, out0);
+  }
+}
+
 __global__ __launch_bounds__(256) void rank_accuracy_kernel(int count, const float* __restrict__ a,
                                                             const float* __restrict__ b,
                                                             const float* __restrict__ label,
@@ -437,6 +658,11 @@ int rank_map_mrr(int n, int fixed_axis, const float* prob, const float* label, c
                        label, group, 0, 0, map_out, mrr_out, effective);
     return launch_status();
   }
+  if (n > kRankSmall && n <= kRankMid && !libstd) {  // a test split's worth (1,517 candidates): still one launch
+    hipLaunchKernelGGL(rank_mid_kernel<0>, dim3(1), dim3(1024), 0, s, n, fixed_axis + 1, fixed_axis, 1, prob,
+                       label, group, 0, 0, map_out, mrr_out, effective);
+    return launch_status();
+  }
   const RankWs lay = rank_ws(n);
   if (!ws || ws_bytes < lay.temp) return MMS_ERR_WORKSPACE;
   char* base = static_cast<char*>(ws);
@@ -477,6 +703,12 @@ int rank_auc(int n, int dim, int fixed_axis, int inner, const float* prob, const
   const bool libstd = rank_tie_mode() == MMS_RANK_TIES_LIBSTDCXX;
   if (n > 0 && n <= kRankSmall && !libstd) {
     hipLaunchKernelGGL(rank_small_kernel<1>, dim3(1), dim3(1024), 0, s, n, dim, fixed_axis, inner, prob, label,
+                       static_cast<const float*>(nullptr), has_ignore, ignore_label, auc_out,
+                       static_cast<float*>(nullptr), static_cast<int*>(nullptr));
+    return launch_status();
+  }
+  if (n > kRankSmall && n <= kRankMid && !libstd) {
+    hipLaunchKernelGGL(rank_mid_kernel<1>, dim3(1), dim3(1024), 0, s, n, dim, fixed_axis, inner, prob, label,
                        static_cast<const float*>(nullptr), has_ignore, ignore_label, auc_out,
                        static_cast<float*>(nullptr), static_cast<int*>(nullptr));
     return launch_status();
