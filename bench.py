@@ -28,11 +28,14 @@ start event, `--lead-in` (64) UNTIMED steps of the same walk are enqueued on rin
 the region's: the device is busy while the host enqueues the start event and the region's first
 hipGraph, so a short region (the driver's --steps 20) does not count host submission latency as
 kernel time; what remains of a short region's fixed cost (two event packets and a graph boundary,
-about 9 us) is visible next to `roofline.long_region`, the same walk over 2048 steps.  Steps are captured into hipGraphs of up
-to GROUP steps (launch-bound inner loop).  N > 1 shards pairs over ranks (weak scaling: 4096 pairs
+about 9 us) is visible next to `roofline.long_region`, the same walk over 2048 steps.  Steps are ALWAYS captured into
+hipGraphs of up to GROUP steps (round 3: a region launched kernel by kernel from the host is only as good as the host is
+idle; `--launch eager` keeps that mode for comparison).  N > 1 shards pairs over ranks (weak scaling: 4096 pairs
 per GPU) and all-gathers the per-pair scores of each GROUP of steps with one RCCL call on a side
-stream, overlapped with the next group's compute; `--workload cfg5` / `cfg4` are the
-strong-scaling legs of the two BASELINE configurations that are multi-GPU by definition.
+stream, overlapped with the next group's compute, and adds `config.strong_split_variant` (ONE 4096-pair batch split over
+the ranks, gather per step); `--workload cfg5` (`--f16-distance ordered|tree`) / `cfg4` are the strong-scaling legs of
+the two BASELINE configurations that are multi-GPU by definition.  `python bench.py --gpus N` typed as is starts its own
+N rank processes (launch_ranks); the torchrun form works too.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
