@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64 * (GW + 1)) void embed_bwd_seg_kernel(
 
 // bias_diff += column sums of top_diff (caffe_cpu_gemv in the reference, embed_layer.cpp:176-178: BLAS order, 1e-5
 // bar).  Round 3: the first cut gave each of 50 threads a 512-row dependent load-add loop -- 104 us per Embed layer at
-// the driver's batch, 70 % of a whole training step of network_v4 (profiles/r03_v4_step_kernel_stats.csv).  Now a
+// the driver's batch, 70 % of a whole training step of network_v4 (profiles/r03_v4_step_kernel_stats.txt).  Now a
 // workgroup owns 128 rows as LANES row lanes x 64 columns, eight independent loads in flight per thread, the lanes
 // folded through LDS in a fixed order.  For small batches the two launches ride along with launches that leave the
 // chip idle anyway: the partial sums in the workgroups NEXT to the one-workgroup inverted-index build, the final sum

@@ -1,7 +1,7 @@
 """tools/v4_step_probe.py -- dev probe: the training step of the reference's network_v4 through the library's own layers
 (do_trec_qa_clean.py:452-470 read as data): Embed x 2 (one shared 50-d table, bias) -> SimCross dist_mode 2, M = 4, bias
 -> backward -> Embed backward x 2.  Batch 50, 40 words, vocabulary 20,000, sentences zero-padded to 40 words.
-Run under rocprofv3 --kernel-trace --stats for the per-kernel breakdown (profiles/r03_v4_step_kernel_stats.csv)."""
+Run under rocprofv3 --kernel-trace --stats for the per-kernel breakdown (profiles/r03_v4_step_kernel_stats.txt)."""
 import sys
 import os
 import torch
