@@ -1174,14 +1174,25 @@ def other_configs(torch, capi):
     dtab, debias = torch.zeros_like(tab), torch.zeros_like(ebias)
     wsv = capi.Workspace()
 
+    pidx = capi.EmbedPairIndex()
+
     def v4_step():
+        # both Embed forwards in one launch, the inverted index of the word ids built beside them (it depends on the
+        # ids alone); Net::Backward reaches the later layer (w2v_a) first, so it is layer 0 of the pair in both calls
+        capi.embed_forward_pair(ia, iq, tab, ae.view(-1, Dv), qe.view(-1, Dv), bias=ebias, index=pidx)
+        capi.simcross_forward(2, qe, ae, tv, W=Wv, bias=bv, ws=wsv)
+        capi.simcross_backward(2, qe, ae, tv, dtv, dqe, dae, W=Wv, bias_term=True, dW=dWv, dbias=dbv, ws=wsv)
+        capi.embed_backward_pair_indexed(ia, iq, dae.view(-1, Dv), dqe.view(-1, Dv), dtab, pidx, bias_diff=debias)
+    us = _graph_time(torch, v4_step, iters=16)
+
+    def v4_step_plain():
         capi.embed_forward(iq, tab, qe.view(-1, Dv), bias=ebias)
         capi.embed_forward(ia, tab, ae.view(-1, Dv), bias=ebias)
         capi.simcross_forward(2, qe, ae, tv, W=Wv, bias=bv, ws=wsv)
         capi.simcross_backward(2, qe, ae, tv, dtv, dqe, dae, W=Wv, bias_term=True, dW=dWv, dbias=dbv, ws=wsv)
-        # Net::Backward runs the later layer (w2v_a) first; both into the one shared table diff, as ONE pass
-        capi.embed_backward_pair(ia, iq, dae.view(-1, Dv), dqe.view(-1, Dv), dtab, bias_diff=debias, ws=wsv)
-    us = _graph_time(torch, v4_step, iters=16)
+        capi.embed_backward(ia, dae.view(-1, Dv), dtab, bias_diff=debias, ws=wsv)
+        capi.embed_backward(iq, dqe.view(-1, Dv), dtab, bias_diff=debias, ws=wsv)
+    us_plain = _graph_time(torch, v4_step_plain, iters=16)
     parts = {}
     for nm, fn in (("embed_forward_x2", lambda: (capi.embed_forward(iq, tab, qe.view(-1, Dv), bias=ebias),
                                                  capi.embed_forward(ia, tab, ae.view(-1, Dv), bias=ebias))),
@@ -1191,12 +1202,17 @@ def other_configs(torch, capi):
                    ("embed_backward_x2_as_two_calls", lambda: (capi.embed_backward(ia, dae.view(-1, Dv), dtab, bias_diff=debias, ws=wsv),
                                                                capi.embed_backward(iq, dqe.view(-1, Dv), dtab, bias_diff=debias, ws=wsv))),
                    ("embed_backward_pair", lambda: capi.embed_backward_pair(ia, iq, dae.view(-1, Dv), dqe.view(-1, Dv), dtab,
-                                                                            bias_diff=debias, ws=wsv))):
+                                                                            bias_diff=debias, ws=wsv)),
+                   ("embed_forward_pair_with_index", lambda: capi.embed_forward_pair(ia, iq, tab, ae.view(-1, Dv), qe.view(-1, Dv),
+                                                                                     bias=ebias, index=pidx)),
+                   ("embed_backward_pair_indexed", lambda: capi.embed_backward_pair_indexed(ia, iq, dae.view(-1, Dv), dqe.view(-1, Dv),
+                                                                                           dtab, pidx, bias_diff=debias))):
         parts[nm] = _graph_time(torch, fn, iters=16)
     out["network_v4_training_step_batch50"] = {
-        "us_per_step": us, "pairs_per_s": Bt / (us * 1e-6), "parts_us": parts,
-        "note": "Embed x2 -> SimCross bilinear M=4 + bias -> backward -> both Embed backwards as one pass over the shared "
-                "table (mms_embed_backward_pair_f32), through the C ABI, graph-replayed; parts timed alone"}
+        "us_per_step": us, "pairs_per_s": Bt / (us * 1e-6), "us_per_step_layer_by_layer_calls": us_plain, "parts_us": parts,
+        "note": "Embed x2 (one launch, inverted index of the word ids built beside the gathers) -> SimCross bilinear M=4 + "
+                "bias -> backward -> both Embed backwards as one pass over the shared table from that index, through the C "
+                "ABI, graph-replayed; us_per_step_layer_by_layer_calls: the same step as six per-layer calls; parts alone"}
     del tab, iq, ia, qe, ae, Wv, bv, tv, dtv, dqe, dae, dWv, dbv, dtab
 
     # PairRankLoss alone (forward s*5*count bytes, backward s*5*count): the batch of cfg 2 and a

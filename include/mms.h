@@ -444,6 +444,21 @@ int mms_embed_backward_f32(int M, int N, int K, const float* index, const float*
 int mms_embed_backward_pair_f32(int M0, int M1, int N, int K, const float* index0, const float* top_diff0,
                                 const float* index1, const float* top_diff1, float* weight_diff, float* bias_diff,
                                 void* workspace, size_t workspace_bytes, void* stream);
+/* The same pair with the inverted index built in the FORWARD pass: it depends on the word ids alone, the one-workgroup
+ * sort that builds it takes ~14 us, and beside the forward's gathers it costs nothing.
+ *   mms_embed_forward_pair_f32: top0 = Embed(index0), top1 = Embed(index1) (embed_layer.cpp:135-152 twice) in ONE
+ *       launch; with index_workspace != NULL (mms_embed_workspace_bytes(M0 + M1, N)) and
+ *       mms_embed_pair_index_supported(M0, M1, K) it also writes the index of the ids in the order (index0, index1).
+ *   mms_embed_backward_pair_indexed_f32: mms_embed_backward_pair_f32 minus the index build; index0 / index1 and the
+ *       workspace must be the ones the forward call was given, in the same order, and the workspace untouched since.
+ *       (For the reference's nets pass the LATER layer of the file as layer 0 in BOTH calls: Net::Backward reaches it first.) */
+int mms_embed_pair_index_supported(int M0, int M1, int K);
+int mms_embed_forward_pair_f32(int M0, int M1, int N, int K, const float* index0, const float* index1,
+                               const float* weight, const float* bias, float* top0, float* top1, void* index_workspace,
+                               size_t index_workspace_bytes, void* stream);
+int mms_embed_backward_pair_indexed_f32(int M0, int M1, int N, int K, const float* index0, const float* top_diff0,
+                                        const float* index1, const float* top_diff1, float* weight_diff, float* bias_diff,
+                                        void* index_workspace, size_t index_workspace_bytes, void* stream);
 
 size_t mms_embed_workspace_bytes(int M, int N);
 

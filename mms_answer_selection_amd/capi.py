@@ -45,6 +45,9 @@ _SIGNATURES = {
     "mms_embed_forward_f32": (_i, [_i, _i, _i] + [_vp] * 5),
     "mms_embed_backward_f32": (_i, [_i, _i, _i] + [_vp] * 5 + [_sz, _vp]),
     "mms_embed_backward_pair_f32": (_i, [_i, _i, _i, _i] + [_vp] * 6 + [_vp, _sz, _vp]),
+    "mms_embed_pair_index_supported": (_i, [_i, _i, _i]),
+    "mms_embed_forward_pair_f32": (_i, [_i, _i, _i, _i] + [_vp] * 6 + [_vp, _sz, _vp]),
+    "mms_embed_backward_pair_indexed_f32": (_i, [_i, _i, _i, _i] + [_vp] * 6 + [_vp, _sz, _vp]),
     "mms_feed_gather_rows_f32": (_i, [_i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "mms_simcross_workspace_bytes_f64": (_sz, [_i] * 6),
     "mms_simcross_forward_f64": (_i, [_i] * 6 + [_vp] * 8 + [_sz, _vp]),
@@ -425,6 +428,46 @@ def embed_backward_pair(index0, index1, top_diff0, top_diff1, weight_diff, bias_
                                             _ptr(index1, "index1"), _ptr(top_diff1, "top_diff1"),
                                             _ptr(weight_diff, "weight_diff", True), _ptr(bias_diff, "bias_diff", True),
                                             wsp, wsb, _stream()), "mms_embed_backward_pair_f32")
+
+
+class EmbedPairIndex:
+    """The inverted index of two Embed layers' word ids, built by embed_forward_pair and consumed by
+    embed_backward_pair(index=...): its own buffer (nothing else may write it between the two calls)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self.buf.data_ptr(), self.buf.numel()
+
+
+def embed_forward_pair(index0, index1, weight, top0, top1, bias=None, index=None):
+    """top0 = Embed(index0), top1 = Embed(index1) in one launch; `index` (an EmbedPairIndex): also build the inverted
+    index of the ids for embed_backward_pair.  Returns True if the index was built."""
+    M0, M1, (K, N) = index0.numel(), index1.numel(), weight.shape
+    wsp, wsb, built = None, 0, False
+    if index is not None and lib().mms_embed_pair_index_supported(M0, M1, K):
+        wsp, wsb = index.get(lib().mms_embed_workspace_bytes(M0 + M1, N), index0.device)
+        built = True
+    check(lib().mms_embed_forward_pair_f32(M0, M1, N, K, _ptr(index0, "index0"), _ptr(index1, "index1"),
+                                           _ptr(weight, "weight"), _ptr(bias, "bias", True), _ptr(top0, "top0"),
+                                           _ptr(top1, "top1"), wsp, wsb, _stream()), "mms_embed_forward_pair_f32")
+    return built
+
+
+def embed_backward_pair_indexed(index0, index1, top_diff0, top_diff1, weight_diff, index, bias_diff=None):
+    """embed_backward_pair with the index embed_forward_pair(index0, index1, ..., index=index) built (same order)."""
+    M0, M1, (K, N) = index0.numel(), index1.numel(), weight_diff.shape
+    if index.buf is None:
+        raise MMSError("embed_backward_pair_indexed: no index was built (embed_forward_pair returned False); use "
+                       "embed_backward_pair")
+    check(lib().mms_embed_backward_pair_indexed_f32(M0, M1, N, K, _ptr(index0, "index0"), _ptr(top_diff0, "top_diff0"),
+                                                    _ptr(index1, "index1"), _ptr(top_diff1, "top_diff1"),
+                                                    _ptr(weight_diff, "weight_diff", True), _ptr(bias_diff, "bias_diff", True),
+                                                    index.buf.data_ptr(), index.buf.numel(), _stream()),
+          "mms_embed_backward_pair_indexed_f32")
 
 
 def feed_gather_rows(src, first, rows, dst, perm=None):

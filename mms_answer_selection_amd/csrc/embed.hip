@@ -201,15 +201,9 @@ __global__ __launch_bounds__(256) void embed_bias_finish_kernel(int chunks, int 
 // of the head positions and their count -- in ONE workgroup and one launch instead of the dozen
 // launches of the device-wide sort + select (each a few microseconds of pure latency).
 constexpr int kPrepThreads = 1024, kPrepItems = 4, kPrepMax = kPrepThreads * kPrepItems;
-__global__ __launch_bounds__(kPrepThreads) void embed_prep_small_kernel(
-    int M, int K, unsigned bits, EmbedSrc src, unsigned* __restrict__ keys,
-    unsigned* __restrict__ vals, unsigned* __restrict__ heads, unsigned* __restrict__ nseg,
-    int N, float* __restrict__ bias_partial) {
-  if (blockIdx.x > 0) {                          // riders: the bias gradient's partial sums (bias_partial != null)
-    __shared__ float red[kPrepThreads / 64][64];
-    embed_bias_partial_body<kPrepThreads / 64>((int)blockIdx.x - 1, M, N, src, bias_partial, red);
-    return;
-  }
+__device__ __forceinline__ void embed_prep_body(int M, int K, unsigned bits, const EmbedSrc& src,
+                                                unsigned* __restrict__ keys, unsigned* __restrict__ vals,
+                                                unsigned* __restrict__ heads, unsigned* __restrict__ nseg) {
   using sort_t = rocprim::block_radix_sort<unsigned, kPrepThreads, kPrepItems, unsigned>;
   using scan_t = rocprim::block_scan<unsigned, kPrepThreads>;
   __shared__ union { typename sort_t::storage_type sort; typename scan_t::storage_type scan; } tmp;
@@ -248,6 +242,45 @@ __global__ __launch_bounds__(kPrepThreads) void embed_prep_small_kernel(
     if (flag[i]) heads[before++] = (unsigned)(t * kPrepItems + i);
   }
   if (t == 0) nseg[0] = total;
+}
+__global__ __launch_bounds__(kPrepThreads) void embed_prep_small_kernel(
+    int M, int K, unsigned bits, EmbedSrc src, unsigned* __restrict__ keys,
+    unsigned* __restrict__ vals, unsigned* __restrict__ heads, unsigned* __restrict__ nseg,
+    int N, float* __restrict__ bias_partial) {
+  if (blockIdx.x > 0) {                          // riders: the bias gradient's partial sums (bias_partial != null)
+    __shared__ float red[kPrepThreads / 64][64];
+    embed_bias_partial_body<kPrepThreads / 64>((int)blockIdx.x - 1, M, N, src, bias_partial, red);
+    return;
+  }
+  embed_prep_body(M, K, bits, src, keys, vals, heads, nseg);
+}
+
+// Forward of two Embed layers over ONE table in one launch, with the inverted index of their concatenated word ids
+// built beside the gathers (workgroup 0): the index depends on the ids alone, the one-workgroup sort that builds it
+// takes 14 us at a lone workgroup's clock, and in the forward it costs nothing -- the gathers and the layers behind
+// them keep the rest of the chip busy.  The backward pass (embed_backward_pair with index_ready) then starts at the
+// segment kernels.
+__global__ __launch_bounds__(kPrepThreads) void embed_fwd_pair_kernel(
+    int M0, int M1, int N, int K, EmbedSrc src, const float* __restrict__ weight, const float* __restrict__ bias,
+    float* __restrict__ top0, float* __restrict__ top1, int build, unsigned bits, unsigned* __restrict__ keys,
+    unsigned* __restrict__ vals, unsigned* __restrict__ heads, unsigned* __restrict__ nseg) {
+  const int M = M0 + M1;
+  if (build && blockIdx.x == 0) {
+    embed_prep_body(M, K, bits, src, keys, vals, heads, nseg);
+    return;
+  }
+  const int n = ((int)blockIdx.x - (build ? 1 : 0)) * (kPrepThreads / 64) + (int)(threadIdx.x >> 6);   // one wave per row
+  if (n >= M) return;
+  const int lane = threadIdx.x & 63;
+  int idx = (int)src.index(n);
+  idx = idx < 0 ? 0 : (idx >= K ? K - 1 : idx);
+  const float* w = weight + (size_t)idx * N;
+  float* t = n < M0 ? top0 + (size_t)n * N : top1 + (size_t)(n - M0) * N;
+  for (int d = lane; d < N; d += 64) {
+    float v = w[d];
+    if (bias) v = 1.0f * (1.0f * bias[d]) + 1.0f * v;   // gemm(M,N,1): alpha*(1*bias) + beta*top, as embed_fwd_kernel
+    t[d] = v;
+  }
 }
 
 // Short segments (nearly every word id: a handful of rows): one WAVE per (id, 64-column slice),
@@ -313,7 +346,8 @@ int embed_forward(int M, int N, int K, const float* index, const float* weight, 
 }
 
 static int embed_backward_src(int M, int N, int K, const EmbedSrc& src,
-                              float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes, hipStream_t s) {
+                              float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes, hipStream_t s,
+                              bool index_ready = false) {
   const EmbedWs lay = embed_ws(M, N);
   if (!ws || ws_bytes < lay.temp) return MMS_ERR_WORKSPACE;
   char* base = static_cast<char*>(ws);
@@ -327,7 +361,14 @@ static int embed_backward_src(int M, int N, int K, const EmbedSrc& src,
     while (bits < 32 && (1ull << bits) < (unsigned long long)K) ++bits;
     auto* heads = reinterpret_cast<unsigned*>(base + lay.heads);
     auto* nseg = reinterpret_cast<unsigned*>(base + lay.nseg);
-    if (M <= kPrepMax && bits < 32) {
+    if (index_ready && M <= kPrepMax && bits < 32) {
+      // keys / vals / heads / nseg of this workspace were written by embed_forward_pair for these very ids
+      if (bias_diff) {
+        hipLaunchKernelGGL(embed_bias_partial_kernel, dim3((unsigned)lay.chunks), dim3(256), 0, s, M, N, src,
+                           reinterpret_cast<float*>(base + lay.partial));
+        bias_rides = true;                          // (the final sum still rides with the short-segment launch)
+      }
+    } else if (M <= kPrepMax && bits < 32) {
       bias_rides = bias_diff != nullptr;
       hipLaunchKernelGGL(embed_prep_small_kernel, dim3(1u + (bias_rides ? (unsigned)lay.chunks : 0u)), dim3(kPrepThreads), 0,
                          s, M, K, bits, src, k1, v1, heads, nseg, N, reinterpret_cast<float*>(base + lay.partial));
@@ -384,9 +425,39 @@ int embed_backward(int M, int N, int K, const float* index, const float* top_dif
 // Same bits as the two calls: a table row's additions keep the order "layer 0's rows ascending, then layer 1's".
 int embed_backward_pair(int M0, int M1, int N, int K, const float* index0, const float* top_diff0, const float* index1,
                         const float* top_diff1, float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes,
-                        hipStream_t s) {
+                        hipStream_t s, int index_ready) {
   const EmbedSrc src{index0, top_diff0, M0, index1, top_diff1};
-  return embed_backward_src(M0 + M1, N, K, src, weight_diff, bias_diff, ws, ws_bytes, s);
+  return embed_backward_src(M0 + M1, N, K, src, weight_diff, bias_diff, ws, ws_bytes, s, index_ready != 0);
+}
+
+// can embed_forward_pair build the index for these sizes?  (the one-workgroup sort: up to 4,096 ids)
+bool embed_pair_index_supported(int M0, int M1, int K) {
+  unsigned bits = 1;
+  while (bits < 32 && (1ull << bits) < (unsigned long long)K) ++bits;
+  return (long long)M0 + M1 <= kPrepMax && bits < 32;
+}
+
+// top0 = Embed(index0), top1 = Embed(index1), one launch; index_ws (optional, embed_workspace_bytes(M0 + M1, N)): the
+// inverted index of the ids in the order (index0, index1) -- hand the SAME workspace and the same order to
+// embed_backward_pair with index_ready = 1
+int embed_forward_pair(int M0, int M1, int N, int K, const float* index0, const float* index1, const float* weight,
+                       const float* bias, float* top0, float* top1, void* index_ws, size_t index_ws_bytes, hipStream_t s) {
+  const int M = M0 + M1;
+  const EmbedWs lay = embed_ws(M, N);
+  const bool build = index_ws != nullptr && embed_pair_index_supported(M0, M1, K);
+  if (build && index_ws_bytes < lay.temp) return MMS_ERR_WORKSPACE;
+  char* base = static_cast<char*>(index_ws);
+  unsigned bits = 1;
+  while (bits < 32 && (1ull << bits) < (unsigned long long)K) ++bits;
+  const EmbedSrc src{index0, nullptr, M0, index1, nullptr};
+  const unsigned rows_per_wg = kPrepThreads / 64;
+  hipLaunchKernelGGL(embed_fwd_pair_kernel, dim3((unsigned)((M + rows_per_wg - 1) / rows_per_wg) + (build ? 1u : 0u)),
+                     dim3(kPrepThreads), 0, s, M0, M1, N, K, src, weight, bias, top0, top1, build ? 1 : 0, bits,
+                     build ? reinterpret_cast<unsigned*>(base + lay.k1) : nullptr,
+                     build ? reinterpret_cast<unsigned*>(base + lay.v1) : nullptr,
+                     build ? reinterpret_cast<unsigned*>(base + lay.heads) : nullptr,
+                     build ? reinterpret_cast<unsigned*>(base + lay.nseg) : nullptr);
+  return launch_status();
 }
 
 // ---- batch feed: rows of a device-resident dataset -> one top blob -----------------

@@ -71,7 +71,10 @@ int embed_backward(int M, int N, int K, const float* index, const float* top_dif
                    float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes, hipStream_t s);
 int embed_backward_pair(int M0, int M1, int N, int K, const float* index0, const float* top_diff0, const float* index1,
                         const float* top_diff1, float* weight_diff, float* bias_diff, void* ws, size_t ws_bytes,
-                        hipStream_t s);
+                        hipStream_t s, int index_ready);
+bool embed_pair_index_supported(int M0, int M1, int K);
+int embed_forward_pair(int M0, int M1, int N, int K, const float* index0, const float* index1, const float* weight,
+                       const float* bias, float* top0, float* top1, void* index_ws, size_t index_ws_bytes, hipStream_t s);
 int euclid_backward_mode();
 void set_euclid_backward_mode(int m);
 int pairrank_hinge_mode();
@@ -483,7 +486,31 @@ int mms_embed_backward_pair_f32(int M0, int M1, int N, int K, const float* index
   if ((long long)M0 + M1 > 0x7fffffffLL || ((long long)M0 + M1) * N > 0x7fffffffLL) return MMS_ERR_INVALID_ARG;
   if (!weight_diff && !bias_diff) return MMS_OK;
   return embed_backward_pair(M0, M1, N, K, index0, top_diff0, index1, top_diff1, weight_diff, bias_diff, workspace,
-                             workspace_bytes, as_stream(stream));
+                             workspace_bytes, as_stream(stream), 0);
+}
+
+int mms_embed_pair_index_supported(int M0, int M1, int K) {
+  return M0 > 0 && M1 > 0 && K > 0 && embed_pair_index_supported(M0, M1, K) ? 1 : 0;
+}
+
+int mms_embed_forward_pair_f32(int M0, int M1, int N, int K, const float* index0, const float* index1,
+                               const float* weight, const float* bias, float* top0, float* top1, void* index_workspace,
+                               size_t index_workspace_bytes, void* stream) {
+  if (M0 <= 0 || M1 <= 0 || N <= 0 || K <= 0 || !index0 || !index1 || !weight || !top0 || !top1) return MMS_ERR_INVALID_ARG;
+  if (((long long)M0 + M1) * N > 0x7fffffffLL) return MMS_ERR_INVALID_ARG;
+  return embed_forward_pair(M0, M1, N, K, index0, index1, weight, bias, top0, top1, index_workspace,
+                            index_workspace_bytes, as_stream(stream));
+}
+
+int mms_embed_backward_pair_indexed_f32(int M0, int M1, int N, int K, const float* index0, const float* top_diff0,
+                                        const float* index1, const float* top_diff1, float* weight_diff, float* bias_diff,
+                                        void* index_workspace, size_t index_workspace_bytes, void* stream) {
+  if (M0 <= 0 || M1 <= 0 || N <= 0 || K <= 0 || !index0 || !top_diff0 || !index1 || !top_diff1) return MMS_ERR_INVALID_ARG;
+  if (((long long)M0 + M1) * N > 0x7fffffffLL) return MMS_ERR_INVALID_ARG;
+  if (!embed_pair_index_supported(M0, M1, K)) return MMS_ERR_UNSUPPORTED;     // no index was built for these sizes
+  if (!weight_diff && !bias_diff) return MMS_OK;
+  return embed_backward_pair(M0, M1, N, K, index0, top_diff0, index1, top_diff1, weight_diff, bias_diff, index_workspace,
+                             index_workspace_bytes, as_stream(stream), 1);
 }
 
 size_t mms_embed_workspace_bytes(int M, int N) { return (M > 0 && N > 0) ? embed_workspace_bytes(M, N) : 0; }

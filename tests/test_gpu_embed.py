@@ -76,6 +76,47 @@ def test_embed_backward_pair_is_the_two_backwards(cfg, oracle, hiplib):
     assert_close(bd.cpu().numpy(), bd2.cpu().numpy(), TOL, "bias_diff pair vs two calls")
 
 
+@pytest.mark.parametrize("cfg", [(2000, 2000, 50, 20000, True), (1200, 2896, 50, 300, True), (3, 5, 7, 4, False),
+                                 (3000, 3000, 50, 2000, True)])
+def test_embed_pair_forward_builds_the_index_the_backward_uses(cfg, oracle, hiplib):
+    """mms_embed_forward_pair_f32 = the two forwards (bit for bit) + the inverted index;
+    mms_embed_backward_pair_indexed_f32 = mms_embed_backward_pair_f32 minus the index build: same bits."""
+    from mms_answer_selection_amd import capi
+    M0, M1, N, K, use_bias = cfg
+    r = rng(5 * M0 + M1 + N)
+    idx = []
+    for M in (M0, M1):
+        i = r.integers(0, K, M)
+        i[r.uniform(size=M) < 0.3] = K - 1
+        idx.append(i.astype(np.float32))
+    weight = r.uniform(-0.08, 0.08, (K, N)).astype(np.float32)
+    bias = r.standard_normal(N).astype(np.float32) if use_bias else None
+    t0 = torch.full((M0, N), float("nan"), device="cuda")
+    t1 = torch.full((M1, N), float("nan"), device="cuda")
+    index = capi.EmbedPairIndex()
+    built = capi.embed_forward_pair(dev(idx[0]), dev(idx[1]), dev(weight), t0, t1, bias=dev(bias), index=index)
+    assert built == (M0 + M1 <= 4096)
+    assert_bitexact(t0.cpu().numpy(), oracle.embed_forward(idx[0], weight, bias), "top0")
+    assert_bitexact(t1.cpu().numpy(), oracle.embed_forward(idx[1], weight, bias), "top1")
+    if not built:
+        with pytest.raises(capi.MMSError):
+            capi.embed_backward_pair_indexed(dev(idx[0]), dev(idx[1]), t0, t1, dev(weight), index)
+        return
+    d0 = r.standard_normal((M0, N)).astype(np.float32)
+    d1 = r.standard_normal((M1, N)).astype(np.float32)
+    wd0 = r.standard_normal((K, N)).astype(np.float32)
+    bd0 = r.standard_normal(N).astype(np.float32)
+    wd_a, bd_a = oracle.embed_backward(idx[0], d0, wd0, bd0)
+    wd_ref, bd_ref = oracle.embed_backward(idx[1], d1, wd_a, bd_a)
+    wd, bd = dev(wd0), dev(bd0)
+    capi.embed_backward_pair_indexed(dev(idx[0]), dev(idx[1]), dev(d0), dev(d1), wd, index, bias_diff=bd)
+    assert_bitexact(wd.cpu().numpy(), wd_ref, "weight_diff from the forward's index")
+    assert_close(bd.cpu().numpy(), bd_ref, TOL, "bias_diff")
+    wd2 = dev(wd0)
+    capi.embed_backward_pair_indexed(dev(idx[0]), dev(idx[1]), dev(d0), dev(d1), wd2, index)       # the index is read-only
+    assert_bitexact(wd2.cpu().numpy(), wd_ref, "second use of the same index")
+
+
 @pytest.mark.parametrize("cfg", [(1517, 40, 40, 50, 20000), (1100, 16, 24, 50, 300), (7, 40, 40, 50, 100),
                                  (5, 9, 13, 33, 40), (3, 40, 40, 300, 500), (600, 1, 1, 20, 64)])
 def test_embed_fused_into_simcross_forward(cfg, oracle, hiplib):
