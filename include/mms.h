@@ -212,6 +212,16 @@ int mms_simcross_euclid_forward_backward_f16(int N, int D, const void* q_f16,
                                              const void* a_f16, const float* top_diff,
                                              float* top, void* dq_f16, void* da_f16,
                                              void* stream);
+/* fp16-STORAGE cosine (dist_mode 0), W1 = W2 = 1 (round 3): q, a, dq, da IEEE half in HBM, scores / norms / top_diff fp32,
+ * fp32 arithmetic on the exactly-widened inputs in the reference's form (sim_cross_layer.cpp:112-139, 226-250: norms
+ * cached, T = q.a / nq / na); within 1e-3 relative of the fp32 layer run on the fp16-rounded inputs (the dot products
+ * are cblas_sdot in the reference: no defined order; the gradients are rounded to half).  norm0 / norm1 may be NULL.
+ * D % 8 == 0, D <= 2048. */
+int mms_simcross_cosine_forward_f16(int N, int D, const void* q_f16, const void* a_f16, float* top, float* norm0,
+                                    float* norm1, void* stream);
+int mms_simcross_cosine_forward_backward_f16(int N, int D, const void* q_f16, const void* a_f16, const float* top_diff,
+                                             float* top, float* norm0, float* norm1, void* dq_f16, void* da_f16,
+                                             void* stream);
 
 /* Device scratch needed by the three calls above (0 is possible). */
 size_t mms_simcross_workspace_bytes(int dist_mode, int N, int W1, int W2, int D,

@@ -41,6 +41,8 @@ _SIGNATURES = {
     "mms_triplet_euclid_step_f32": (_i, [_i, _i, _f, _f] + [_vp] * 11 + [_sz, _vp]),
     "mms_simcross_euclid_forward_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "mms_simcross_euclid_forward_backward_f16": (_i, [_i, _i] + [_vp] * 7),
+    "mms_simcross_cosine_forward_f16": (_i, [_i, _i] + [_vp] * 5 + [_vp]),
+    "mms_simcross_cosine_forward_backward_f16": (_i, [_i, _i] + [_vp] * 8 + [_vp]),
     "mms_embed_workspace_bytes": (_sz, [_i, _i]),
     "mms_embed_forward_f32": (_i, [_i, _i, _i] + [_vp] * 5),
     "mms_embed_backward_f32": (_i, [_i, _i, _i] + [_vp] * 5 + [_sz, _vp]),
@@ -402,6 +404,23 @@ def simcross_euclid_forward_backward_f16(q, a, top_diff, top, dq, da):
         N, D, _ptr(q, "q", dtype=h), _ptr(a, "a", dtype=h), _ptr(top_diff, "top_diff"),
         _ptr(top, "top"), _ptr(dq, "dq", dtype=h), _ptr(da, "da", dtype=h), _stream()),
         "mms_simcross_euclid_forward_backward_f16")
+
+
+def simcross_cosine_forward_backward_f16(q, a, top_diff, top, dq, da, norm0=None, norm1=None):
+    N, D = q.shape[0], q.shape[-1]
+    h = torch.float16
+    check(lib().mms_simcross_cosine_forward_backward_f16(
+        N, D, _ptr(q, "q", dtype=h), _ptr(a, "a", dtype=h), _ptr(top_diff, "top_diff"), _ptr(top, "top"),
+        _ptr(norm0, "norm0", True), _ptr(norm1, "norm1", True), _ptr(dq, "dq", dtype=h), _ptr(da, "da", dtype=h),
+        _stream()), "mms_simcross_cosine_forward_backward_f16")
+
+
+def simcross_cosine_forward_f16(q, a, top, norm0=None, norm1=None):
+    N, D = q.shape[0], q.shape[-1]
+    h = torch.float16
+    check(lib().mms_simcross_cosine_forward_f16(N, D, _ptr(q, "q", dtype=h), _ptr(a, "a", dtype=h), _ptr(top, "top"),
+                                                _ptr(norm0, "norm0", True), _ptr(norm1, "norm1", True), _stream()),
+          "mms_simcross_cosine_forward_f16")
 
 
 def embed_forward(index, weight, top, bias=None):

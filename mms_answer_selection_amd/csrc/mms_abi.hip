@@ -17,6 +17,8 @@ int simcross_elementwise_forward_backward(int mode, int N, int W1, int W2, int D
                                           hipStream_t s);
 int simcross_euclid_rows_f16(int N, int D, const void* q, const void* a, const float* top_diff,
                              float* top, void* dq, void* da, bool bwd, hipStream_t s);
+int simcross_cosine_rows_f16(int N, int D, const void* q, const void* a, const float* top_diff, float* top,
+                             float* norm0, float* norm1, void* dq, void* da, bool bwd, hipStream_t s);
 // bilinear.hip
 size_t bilinear_workspace_bytes(int N, int W1, int W2, int D, int M);
 int bilinear_forward(int N, int W1, int W2, int D, int M, const float* q, const float* a,
@@ -263,6 +265,23 @@ int mms_simcross_euclid_forward_f16(int N, int D, const void* q_f16, const void*
   if (!q_f16 || !a_f16 || !top) return MMS_ERR_INVALID_ARG;
   return simcross_euclid_rows_f16(N, D, q_f16, a_f16, nullptr, top, nullptr, nullptr, false,
                                   as_stream(stream));
+}
+
+int mms_simcross_cosine_forward_f16(int N, int D, const void* q_f16, const void* a_f16, float* top, float* norm0,
+                                    float* norm1, void* stream) {
+  if (N < 0 || D <= 0 || (long long)N * D > 0x7fffffffLL) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q_f16 || !a_f16 || !top) return MMS_ERR_INVALID_ARG;
+  return simcross_cosine_rows_f16(N, D, q_f16, a_f16, nullptr, top, norm0, norm1, nullptr, nullptr, false, as_stream(stream));
+}
+
+int mms_simcross_cosine_forward_backward_f16(int N, int D, const void* q_f16, const void* a_f16, const float* top_diff,
+                                             float* top, float* norm0, float* norm1, void* dq_f16, void* da_f16,
+                                             void* stream) {
+  if (N < 0 || D <= 0 || (long long)N * D > 0x7fffffffLL) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q_f16 || !a_f16 || !top_diff || !top || !dq_f16 || !da_f16) return MMS_ERR_INVALID_ARG;
+  return simcross_cosine_rows_f16(N, D, q_f16, a_f16, top_diff, top, norm0, norm1, dq_f16, da_f16, true, as_stream(stream));
 }
 
 int mms_simcross_euclid_forward_backward_f16(int N, int D, const void* q_f16, const void* a_f16,

@@ -696,6 +696,94 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_f16_kernel(
   }
 }
 
+// fp16-STORAGE cosine, W1 = W2 = 1 (round 3; cfg 5's "multi-modal concat embeddings, fp16" with dist_mode 0): one
+// wave per pair, a lane holds NIT half8 of q and of a (all 16-byte loads up front, kept for the backward), fp32
+// arithmetic on the exactly-widened inputs: three tree sums (the reference's cblas_sdot has no defined order), the
+// reference's T = q.a / nq / na with its two successive divisions (sim_cross_layer.cpp:135) and its cached NORMS
+// (:118); backward through per-pair factors as cosine_pair32_kernel (c1 = g / n0 / n1, c2 = g T / n0^2, c3 = g T / n1^2,
+// IEEE divisions once per pair), gradients stored as RNE halves.  Bytes per pair: reads 2 D s + 4, writes 2 D s + 12.
+template <int NIT, bool BWD>
+__global__ __launch_bounds__(256) void cosine_rows_wave_f16_kernel(
+    const _Float16* __restrict__ q, const _Float16* __restrict__ a, const float* __restrict__ top_diff,
+    float* __restrict__ top, float* __restrict__ norm0, float* __restrict__ norm1,
+    _Float16* __restrict__ dq, _Float16* __restrict__ da, int N, int D8) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const half8* q8 = reinterpret_cast<const half8*>(q) + (size_t)row * D8;
+  const half8* a8 = reinterpret_cast<const half8*>(a) + (size_t)row * D8;
+  half8 x[NIT], y[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane + 64 * it, ic = i < D8 ? i : D8 - 1;
+    x[it] = q8[ic];
+    y[it] = a8[ic];
+  }
+  float g = BWD ? top_diff[row] : 0.f;
+  float sqq = 0.f, saa = 0.f, sqa = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if (lane + 64 * it < D8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xf = (float)x[it][e], yf = (float)y[it][e];
+        sqq += xf * xf; saa += yf * yf; sqa += xf * yf;
+      }
+    }
+  }
+  sqq = wave_sum(sqq); saa = wave_sum(saa); sqa = wave_sum(sqa);
+  const float n0 = sqrtf(sqq), n1 = sqrtf(saa);
+  const float T = sqa / n0 / n1;                       // two successive divisions (:135)
+  if (BWD) asm volatile("" : "+v"(g));
+  if (lane == 0) {
+    top[row] = T;
+    if (norm0) norm0[row] = n0;
+    if (norm1) norm1[row] = n1;
+  }
+  if (!BWD) return;
+  const float c1 = g / n0 / n1, c2 = g * T / (n0 * n0), c3 = g * T / (n1 * n1);
+  half8* dq8 = reinterpret_cast<half8*>(dq) + (size_t)row * D8;
+  half8* da8 = reinterpret_cast<half8*>(da) + (size_t)row * D8;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane + 64 * it;
+    if (i < D8) {
+      half8 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xf = (float)x[it][e], yf = (float)y[it][e];
+        o0[e] = (_Float16)(0.f + (c1 * yf - c2 * xf));   // dq = g (a / n0 / n1 - q T / n0^2)   (:239-241)
+        o1[e] = (_Float16)(0.f + (c1 * xf - c3 * yf));   // da = g (q / n0 / n1 - a T / n1^2)   (:243-245)
+      }
+      __builtin_nontemporal_store(o0, dq8 + i);
+      __builtin_nontemporal_store(o1, da8 + i);
+    }
+  }
+}
+
+int simcross_cosine_rows_f16(int N, int D, const void* q, const void* a, const float* top_diff, float* top,
+                             float* norm0, float* norm1, void* dq, void* da, bool bwd, hipStream_t s) {
+  if (N == 0) return MMS_OK;
+  if (D % 8 != 0 || D > 2048 || !aligned16(q) || !aligned16(a) || (bwd && (!aligned16(dq) || !aligned16(da))))
+    return MMS_ERR_UNSUPPORTED;
+  const int D8 = D / 8, nit = (D8 + 63) / 64;
+  const unsigned grid = (unsigned)((N + 3) / 4);
+  const _Float16* qh = static_cast<const _Float16*>(q);
+  const _Float16* ah = static_cast<const _Float16*>(a);
+  _Float16* dqh = static_cast<_Float16*>(dq);
+  _Float16* dah = static_cast<_Float16*>(da);
+#define MMS_COS16(n)                                                                                     \
+  case n:                                                                                                \
+    if (bwd) hipLaunchKernelGGL((cosine_rows_wave_f16_kernel<n, true>), dim3(grid), dim3(256), 0, s, qh, ah, top_diff, top, \
+                                norm0, norm1, dqh, dah, N, D8);                                          \
+    else hipLaunchKernelGGL((cosine_rows_wave_f16_kernel<n, false>), dim3(grid), dim3(256), 0, s, qh, ah, top_diff, top,    \
+                            norm0, norm1, dqh, dah, N, D8);                                              \
+    break;
+  switch (nit) { MMS_COS16(1) MMS_COS16(2) MMS_COS16(3) MMS_COS16(4) default: return MMS_ERR_UNSUPPORTED; }
+#undef MMS_COS16
+  return launch_status();
+}
+
 int simcross_euclid_rows_f16(int N, int D, const void* q, const void* a, const float* top_diff,
                              float* top, void* dq, void* da, bool bwd, hipStream_t s) {
   if (N == 0) return MMS_OK;

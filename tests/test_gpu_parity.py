@@ -264,6 +264,54 @@ def test_euclid_fp16_storage(cfg, oracle, hiplib):
     assert (host(ga).view(np.uint16) == da_ref.astype(np.float16).view(np.uint16)).all(), "da halves"
 
 
+@pytest.mark.parametrize("cfg", [(8192, 1024), (33, 1024), (7, 2048), (5, 8), (9, 304), (1, 512)])
+def test_cosine_fp16_storage(cfg, oracle, hiplib):
+    """fp16-STORAGE cosine sentence vectors (cfg 5's dtype with dist_mode 0): fp32 arithmetic on the widened halves,
+    against the fp32 oracle run on the same fp16-rounded inputs.  Scores and cached norms within 1e-5 (the dot
+    products are cblas_sdot in the reference, no defined order); gradients are stored as halves, so they are held to
+    the configuration's 1e-3 bar and, tighter, to one half ulp-pair of the fp32 gradient."""
+    from mms_answer_selection_amd import capi
+    N, D = cfg
+    r = rng(11 * N + D)
+    qf, af = qa(r, N, 1, 1, D)
+    qh, ah = qf.astype(np.float16), af.astype(np.float16)
+    dT = r.standard_normal((N, 1, 1, 1)).astype(np.float32)
+    q32, a32 = qh.astype(np.float32), ah.astype(np.float32)
+    top_ref, n0_ref, n1_ref = oracle.simcross_forward(0, q32, a32)
+    dq_ref, da_ref, _, _ = oracle.simcross_backward(0, q32, a32, top_ref, dT, norm0=n0_ref, norm1=n1_ref)
+    qd, ad = torch.from_numpy(qh).cuda(), torch.from_numpy(ah).cuda()
+    mk16 = lambda: torch.full(qh.shape, float("nan"), dtype=torch.float16, device="cuda")
+    top, n0, n1 = nan_like(top_ref.shape), nan_like(n0_ref.shape), nan_like(n1_ref.shape)
+    capi.simcross_cosine_forward_f16(qd, ad, top, n0, n1)
+    assert_close(host(top), top_ref, 1e-5, "top (forward only)")
+    assert_close(host(n0), n0_ref, 1e-5, "norm0")
+    assert_close(host(n1), n1_ref, 1e-5, "norm1")
+    top2, gq, ga = nan_like(top_ref.shape), mk16(), mk16()
+    capi.simcross_cosine_forward_backward_f16(qd, ad, dev(dT), top2, gq, ga)      # norms optional
+    assert_bitexact(host(top2), host(top), "fused top == forward-only top")
+    for got, ref, what in ((gq, dq_ref, "dq"), (ga, da_ref, "da")):
+        g = host(got).astype(np.float32)
+        assert_close(g, ref, 1e-3, what)
+        # half rounding of a value within 1e-5 of the fp32 gradient: <= 2^-11 relative per element + the 1e-5 slack
+        assert (np.abs(g - ref) <= np.abs(ref) * 2.0 ** -10 + 1e-5 * max(1.0, np.abs(ref).max()) + 2.0 ** -24).all(), what
+    top3, gq3, ga3 = nan_like(top_ref.shape), mk16(), mk16()
+    capi.simcross_cosine_forward_backward_f16(qd, ad, dev(dT), top3, gq3, ga3)
+    assert (host(gq3).view(np.uint16) == host(gq).view(np.uint16)).all(), "deterministic"
+    assert (host(ga3).view(np.uint16) == host(ga).view(np.uint16)).all(), "deterministic"
+
+
+def test_cosine_fp16_storage_refuses_what_it_cannot_do(hiplib):
+    from mms_answer_selection_amd import capi
+    q = torch.zeros((4, 1, 12), dtype=torch.float16, device="cuda")           # D % 8 != 0
+    top = torch.zeros((4, 1, 1, 1), device="cuda")
+    with pytest.raises(capi.MMSError):
+        capi.simcross_cosine_forward_f16(q, q, top)
+    q = torch.zeros((4, 1, 4096), dtype=torch.float16, device="cuda")          # D > 2048
+    with pytest.raises(capi.MMSError):
+        capi.simcross_cosine_forward_f16(q, q, top)
+    capi.simcross_cosine_forward_f16(q[:0], q[:0], top[:0])                    # N == 0 is a no-op
+
+
 @pytest.mark.parametrize("cfg", [(8192, 1024), (33, 1024), (17, 2048), (9, 304), (64, 512)])
 def test_euclid_fp16_storage_tree_mode(cfg, oracle, hiplib):
     """The opt-in tree sum of the fp16-storage path (no ordered chain): SURVEY 8(d) holds cfg 5 to 1e-3 relative
