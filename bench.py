@@ -1252,7 +1252,14 @@ def other_configs(torch, capi):
             "f16_distance": mode + (": the reference's d-ascending fp32 sum, scores bit-identical" if mode == "ordered"
                                     else ": fixed tree sum, ~1e-6 relative (the configuration's bar is 1e-3)")}
     capi.set_f16_distance_mode("ordered")
-    del qh, ah, dT, top, dqh, dah
+    # the same shard with dist_mode 0 (cosine): norms cached as the reference does, one launch
+    n0c, n1c = torch.empty(N, 1, device="cuda"), torch.empty(N, 1, device="cuda")
+    us = _graph_time(torch, lambda: capi.simcross_cosine_forward_backward_f16(qh, ah, dT, top, dqh, dah, n0c, n1c))
+    out["cfg5_shard_8192x1024_fp16_storage_cosine_fused"] = {
+        "us_per_step": us, "pairs_per_s": N / (us * 1e-6),
+        "frac_hbm_moved_bytes": (b_moved + 8.0 * N) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": "hbm",
+        "dtype": "f16 storage / f32 arithmetic"}
+    del qh, ah, dT, top, dqh, dah, n0c, n1c
     # cfg 4: scoring only -- the TREC-QA test split (1517 candidates, 40 x 40 word grids, Dw = 50),
     # whole and as the 190-candidate shard one of 8 GPUs scores, plus MAP + MRR on 1517 sentence scores
     for name, n in (("cfg4_scoring_1517x40x40x50_forward", 1517), ("cfg4_shard_190x40x40x50_forward", 190)):

@@ -41,7 +41,7 @@ extern "C" {
 /* 0.2.0: mms_embed_simcross_forward_f32 gained `embed_bias`, mms_rank_workspace_bytes and the mms_layer_t option
  * table changed (round 2), the triplet workspace carries the arrival words and must be initialised (round 3).
  * A host built against another header must refuse to run: compare mms_version() with MMS_VERSION at start-up. */
-#define MMS_VERSION 200
+#define MMS_VERSION 210
 
 enum {
   MMS_OK = 0,
@@ -238,6 +238,22 @@ size_t mms_simcross_workspace_bytes(int dist_mode, int N, int W1, int W2, int D,
 int mms_simmatrix_forward_f32(int N, int K1, int K2, const float* q,
                               const float* a, const float* W, float* top,
                               float* qw_scratch, void* stream);
+
+/* The same forward for a caller that owns a workspace (mms_simmatrix_workspace_bytes, the backward's; no
+ * initialisation needed): with it, and N >= 2048 pairs, Q*W runs on the BF16 matrix pipe at fp32 accuracy -- every
+ * fp32 operand is the exact sum of three bf16 values, the six partial products of weight >= 2^-16 are accumulated in
+ * fp32 (csrc/bx3_gemm.h; the three dropped are <= 2^-24 relative) -- 16 x the fp32 pipe's rate per instruction for 6 x
+ * the instructions.  Results agree with the fp32-MFMA product of mms_simmatrix_forward_f32 to fp32 rounding (both are
+ * inside the 1e-5 contract of this BLAS-backed layer: the reference calls cblas_sgemm, no defined order); an input
+ * holding an infinity yields NaN where the fp32 product yields inf.  The backward calls below take the same route for
+ * dq (and da) when handed this workspace.  mms_set_matrix_mode(1) pins every product to the fp32 pipe (process-wide;
+ * 0 = default), mms_get_matrix_mode() reads it. */
+int mms_simmatrix_forward_ws_f32(int N, int K1, int K2, const float* q,
+                                 const float* a, const float* W, float* top,
+                                 float* qw_scratch, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+int mms_set_matrix_mode(int mode);
+int mms_get_matrix_mode(void);
 
 /* Replaces SimMatrixLayer<float>::Backward_cpu / Backward_gpu
  *   src/caffe/layers/sim_matrix_layer.cpp:68-95, sim_matrix_layer.cu:43-46.

@@ -29,6 +29,9 @@ _SIGNATURES = {
     "mms_embed_simcross_forward_f32": (_i, [_i] * 6 + [_vp] * 8),
     "mms_embed_simcross_bilinear_forward_f32": (_i, [_i] * 6 + [_vp] * 8),
     "mms_simmatrix_forward_f32": (_i, [_i] * 3 + [_vp] * 6),
+    "mms_simmatrix_forward_ws_f32": (_i, [_i] * 3 + [_vp] * 6 + [_sz, _vp]),
+    "mms_set_matrix_mode": (_i, [_i]),
+    "mms_get_matrix_mode": (_i, []),
     "mms_simmatrix_backward_f32": (_i, [_i] * 3 + [_vp] * 4 + [_i] * 3 + [_vp] * 4 + [_sz, _vp]),
     "mms_simmatrix_backward_cached_f32": (_i, [_i] * 3 + [_vp] * 5 + [_i] * 3 + [_vp] * 4 + [_sz, _vp]),
     "mms_pairrank_workspace_bytes": (_sz, [_i]),
@@ -90,7 +93,7 @@ class MMSError(RuntimeError):
     pass
 
 
-MMS_VERSION = 200      # include/mms.h
+MMS_VERSION = 210      # include/mms.h
 
 
 def lib():
@@ -228,12 +231,29 @@ def embed_simcross_bilinear_forward(index_q, index_a, weight, W, bias, top, embe
         "mms_embed_simcross_bilinear_forward_f32")
 
 
-def simmatrix_forward(q, a, W, top, qw_scratch):
+def simmatrix_forward(q, a, W, top, qw_scratch, ws=None, use_workspace=True):
+    """With a workspace (the default one unless use_workspace=False) the call is mms_simmatrix_forward_ws_f32: Q.W on
+    the bf16 matrix pipe at fp32 accuracy for N >= 2048 (include/mms.h); without, mms_simmatrix_forward_f32."""
     N = q.shape[0]
     K1, K2 = W.shape
-    check(lib().mms_simmatrix_forward_f32(
+    if not use_workspace:
+        check(lib().mms_simmatrix_forward_f32(
+            N, K1, K2, _ptr(q, "q"), _ptr(a, "a"), _ptr(W, "W"), _ptr(top, "top"),
+            _ptr(qw_scratch, "qw_scratch"), _stream()), "mms_simmatrix_forward_f32")
+        return
+    wsp, wsb = (ws or _default_ws).get(lib().mms_simmatrix_workspace_bytes(N, K1, K2), q.device)
+    check(lib().mms_simmatrix_forward_ws_f32(
         N, K1, K2, _ptr(q, "q"), _ptr(a, "a"), _ptr(W, "W"), _ptr(top, "top"),
-        _ptr(qw_scratch, "qw_scratch"), _stream()), "mms_simmatrix_forward_f32")
+        _ptr(qw_scratch, "qw_scratch"), wsp, wsb, _stream()), "mms_simmatrix_forward_ws_f32")
+
+
+def set_matrix_mode(mode):
+    """"bf16x3" (default: exact three-way bf16 splits on the bf16 pipe) or "fp32" (fp32 MFMA); include/mms.h."""
+    check(lib().mms_set_matrix_mode({"bf16x3": 0, "fp32": 1}[mode]), "mms_set_matrix_mode")
+
+
+def get_matrix_mode():
+    return ("bf16x3", "fp32")[lib().mms_get_matrix_mode()]
 
 
 def simmatrix_backward(q, a, W, top_diff, dq, da, dW, param_propagate_down=True,

@@ -24,6 +24,7 @@
 
 #include "mms_common.h"
 #include "panel_gemm.h"
+#include "bx3_gemm.h"
 
 namespace mms {
 
@@ -859,7 +860,7 @@ static bool pair_bwd_fits(int N, int W1, int W2, int D, int M) {      // = pair_
 // of the generic GEMM + rowdot / rowscale launches: 45 + 136 us -> the SimMatrix figures (recomputing Q.W).
 size_t simmatrix_workspace_bytes(int N, int K1, int K2);
 int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, const float* W, float* top, float* qw,
-                      hipStream_t s, const float* rd_bias);
+                      hipStream_t s, const float* rd_bias, void* ws = nullptr, size_t ws_bytes = 0);
 int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, const float* W,
                        const float* top_diff, int ppd, int pd0, int pd1, float* dq, float* da,
                        float* dW, const float* qw, void* ws, size_t ws_bytes, hipStream_t s);
@@ -1346,7 +1347,11 @@ int bilinear_forward(int N, int W1, int W2, int D, int M, const float* q, const 
   const BilinearWs lay = bilinear_ws(N, W1, W2, D, M);
   if (!ws || ws_bytes < lay.total) return MMS_ERR_WORKSPACE;
   if (bilinear_as_simmatrix(W1, W2, M))
-    return simmatrix_forward(N, D, D, q, a, W, top, static_cast<float*>(ws), s, bias);
+  {
+    const size_t off = round_up((size_t)N * D * sizeof(float), 256);      // [Q.W][SimMatrix's own workspace]
+    return simmatrix_forward(N, D, D, q, a, W, top, static_cast<float*>(ws), s, bias, static_cast<char*>(ws) + off,
+                             ws_bytes - off);
+  }
   // large batches only (evaluation: the 1517 TREC-QA test candidates, 89 -> 59 us): at the training batch of
   // 50 pairs both forms sit at the launch floor and the two small GEMMs are marginally quicker
   if (W1 <= PF_ROWS && W2 <= PF_ROWS && D <= 16 * PF_TD && W1 * W2 > 1 && N >= 512) {
@@ -1531,9 +1536,21 @@ int bilinear_backward(int N, int W1, int W2, int D, int M, const float* q, const
 
 // ---------------------------------- SimMatrix -------------------------------
 struct SimMatrixWs {
-  size_t u_off, part_off, wt_off, total;
+  size_t u_off, part_off, wt_off, img_off, total;
   int ksplit, kchunk;
 };
+
+// Which matrix pipe the tall-times-weight products of the learned-metric paths run on (mms_set_matrix_mode):
+// 0 (default) = the bf16 pipe on exact three-way splits of the fp32 operands (bx3_gemm.h), 1 = fp32 MFMA (panel_gemm.h).
+static int g_matrix_mode = 0;
+int set_matrix_mode(int mode) {
+  if (mode != 0 && mode != 1) return MMS_ERR_INVALID_ARG;
+  g_matrix_mode = mode;
+  return MMS_OK;
+}
+int get_matrix_mode() { return g_matrix_mode; }
+// below this many rows the fp32 kernel's 64-row panels fill the chip better and the split launch is not worth its 3 us
+static bool bx3_rows_worth(int M) { return M >= 2048; }
 static SimMatrixWs simmatrix_ws(int N, int K1, int K2) {
   SimMatrixWs w{};
   w.ksplit = pick_ksplit(K1, K2, N, &w.kchunk);
@@ -1542,14 +1559,30 @@ static SimMatrixWs simmatrix_ws(int N, int K1, int K2) {
   w.u_off = 0;
   w.part_off = round_up((size_t)N * K2 * sizeof(float), 256);
   w.wt_off = w.part_off + round_up((size_t)(psplit > w.ksplit ? psplit : w.ksplit) * K1 * K2 * sizeof(float), 256);
-  w.total = w.wt_off + round_up((size_t)K1 * K2 * sizeof(float), 256);      // W^T for the dq product
+  w.img_off = w.wt_off + round_up((size_t)K1 * K2 * sizeof(float), 256);    // W^T for the dq product (fp32 MFMA mode)
+  const size_t ia = bx3_image_bytes(K2, K1), ib = bx3_image_bytes(K1, K2);  // the split image of W (forward) or W^T (dq)
+  w.total = w.img_off + round_up(ia > ib ? ia : ib, 256);
   return w;
 }
 size_t simmatrix_workspace_bytes(int N, int K1, int K2) { return simmatrix_ws(N, K1, K2).total; }
 
 int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, const float* W,
-                      float* top, float* qw, hipStream_t s, const float* rd_bias) {
+                      float* top, float* qw, hipStream_t s, const float* rd_bias, void* ws, size_t ws_bytes) {
   // qw = Q W  (:60-61) ; top_i = a_i . qw_i  (:62-64)
+  if (g_matrix_mode == 0 && ws && bx3_rows_worth(N)) {
+    const SimMatrixWs lay = simmatrix_ws(N, K1, K2);
+    Bx3Args b{};
+    b.M = N; b.N = K2; b.K = K1; b.A = q; b.lda = K1; b.C = qw; b.ldc = K2;
+    b.Y = a; b.ldy = K2; b.rowdot = top; b.rd_stride = 1; b.rd_bias = rd_bias;
+    if (ws_bytes >= lay.total && bx3_eligible(b)) {
+      bx3_u4* img = reinterpret_cast<bx3_u4*>(static_cast<char*>(ws) + lay.img_off);
+      b.img = img;
+      // the image of W; its launch also zeroes the scores when two column groups add their halves into them
+      bx3_split_b(W, K2, 1, K1, K2, img, s, bx3_groups(K2) == 2 ? top : nullptr, 1, N);
+      bx3_launch(b, s);
+      return launch_status();
+    }
+  }
   {
     // one launch: the row dot is the product's epilogue
     PanelArgs p = panel_args(N, K2, K1, q, K1, W, K2, qw, K2);
@@ -1577,7 +1610,17 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
   // will the dq product take the panel kernel (and need W^T)?  Then its transpose rides in the dW reduction's launch.
   float* const Wt_ws = (ws && ws_bytes >= lay.total) ? reinterpret_cast<float*>(static_cast<char*>(ws) + lay.wt_off) : nullptr;
   bool dq_panel = false, wt_done = false;
-  if (pd0 && Wt_ws) {
+  Bx3Args bq{};                                 // the dq product on the bf16 pipe (matrix mode 0), if it can run there
+  bool dq_bx3 = false;
+  if (pd0 && g_matrix_mode == 0 && ws && ws_bytes >= lay.total && bx3_rows_worth(N)) {
+    bq.M = N; bq.N = K1; bq.K = K2; bq.A = a; bq.lda = K2; bq.C = dq; bq.ldc = K1; bq.rowscale = top_diff; bq.stream_c = 1;
+    if (pd1 && qw && (K2 & 3) == 0 && K2 >= 8) {
+      bq.side_in = qw; bq.side_out = da; bq.side_scale = top_diff; bq.side_ld = K2; bq.side_cols = K2;
+    }
+    dq_bx3 = bx3_eligible(bq);
+    if (!dq_bx3 && bq.side_in) { bq.side_in = nullptr; bq.side_out = nullptr; bq.side_scale = nullptr; dq_bx3 = bx3_eligible(bq); }
+  }
+  if (pd0 && Wt_ws && !dq_bx3) {
     PanelArgs pq = panel_args(N, K1, K2, a, K2, Wt_ws, K1, dq, K1);
     pq.rowscale = top_diff;
     dq_panel = panel_eligible(pq, true);
@@ -1624,7 +1667,14 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
     }
   }
   bool da_done = false;
-  if (pd0) {
+  if (pd0 && dq_bx3) {
+    // dq_j = dT_j * (W a_j)   (:88, NoTrans, beta 0): B(k, n) = W[n][k], split straight from W's rows
+    bx3_u4* img = reinterpret_cast<bx3_u4*>(static_cast<char*>(ws) + lay.img_off);
+    bq.img = img;
+    bx3_split_b(W, 1, K2, K2, K1, img, s);
+    bx3_launch(bq, s);
+    da_done = bq.side_in != nullptr;
+  } else if (pd0) {
     // dq_j = dT_j * (W a_j)   (:88, NoTrans, beta 0)
     float* Wt = Wt_ws;
     PanelArgs p = panel_args(N, K1, K2, a, K2, Wt, K1, dq, K1);     // B(k, n) = W[n][k] = Wt[k][n]
@@ -1659,6 +1709,19 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
       hipLaunchKernelGGL(rowscale_inplace_ok_kernel, dim3(ew_blocks((long long)N * K2)), dim3(256), 0, s, x,
                          top_diff, da, (long long)N, K2);
     }
+  } else if (pd1 && g_matrix_mode == 0 && ws && ws_bytes >= lay.total && bx3_rows_worth(N) && [&] {
+               // da_j = dT_j * (W^T q_j)   (:88, Trans, beta 0): the forward's product (same kernel, same image, same
+               // k order: the bits of the cached form above), scaled in its epilogue
+               Bx3Args b{};
+               b.M = N; b.N = K2; b.K = K1; b.A = q; b.lda = K1; b.C = da; b.ldc = K2; b.rowscale = top_diff; b.stream_c = 1;
+               if (!bx3_eligible(b)) return false;
+               bx3_u4* img = reinterpret_cast<bx3_u4*>(static_cast<char*>(ws) + lay.img_off);
+               b.img = img;
+               bx3_split_b(W, K2, 1, K1, K2, img, s);
+               bx3_launch(b, s);
+               return true;
+             }()) {
+    // written by the launch above
   } else if (pd1) {
     // da_j = dT_j * (W^T q_j)   (:88, Trans, beta 0)
     PanelArgs p = panel_args(N, K2, K1, q, K1, W, K2, da, K2);

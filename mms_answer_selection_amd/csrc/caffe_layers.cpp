@@ -141,10 +141,13 @@ inline int simcross_backward(int mode, int N, int W1, int W2, int D, int M, cons
 }
 inline size_t simmatrix_ws(float, int N, int K1, int K2) { return mms_simmatrix_workspace_bytes(N, K1, K2); }
 inline size_t simmatrix_ws(double, int, int, int) { return 0; }
-inline int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, const float* W, float* top, float* scr) {
+inline int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, const float* W, float* top, float* scr,
+                             void* ws, size_t wsb) {
+  if (ws) return mms_simmatrix_forward_ws_f32(N, K1, K2, q, a, W, top, scr, ws, wsb, nullptr);   // the layer's own workspace
   return mms_simmatrix_forward_f32(N, K1, K2, q, a, W, top, scr, nullptr);
 }
-inline int simmatrix_forward(int N, int K1, int K2, const double* q, const double* a, const double* W, double* top, double* scr) {
+inline int simmatrix_forward(int N, int K1, int K2, const double* q, const double* a, const double* W, double* top, double* scr,
+                             void*, size_t) {
   return mms_simmatrix_forward_f64(N, K1, K2, q, a, W, top, scr, nullptr);
 }
 inline int simmatrix_backward_cached(int N, int K1, int K2, const float* q, const float* a, const float* W, const float* qw,
@@ -382,7 +385,9 @@ class SimMatrixLayer : public Layer<Dtype> {
   void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) override {
     Dtype* qw = private_qw_ ? qw_.mutable_gpu_data() : bottom[1]->mutable_gpu_diff();
     mms_check(abi::simmatrix_forward(M_, K1_, K2_, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
-                                     this->blobs_[0]->gpu_data(), top[0]->mutable_gpu_data(), qw),
+                                     this->blobs_[0]->gpu_data(), top[0]->mutable_gpu_data(), qw,
+                                     workspace_.count() ? workspace_.mutable_gpu_data() : nullptr,
+                                     (size_t)workspace_.count() * sizeof(Dtype)),
               "mms_simmatrix_forward");
     qw_valid_ = true;
   }

@@ -32,7 +32,9 @@ int embed_bilinear_forward(int N, int W1, int W2, int D, int M, int K, const flo
                            const float* bias, float* top, hipStream_t s);
 size_t simmatrix_workspace_bytes(int N, int K1, int K2);
 int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, const float* W,
-                      float* top, float* qw, hipStream_t s, const float* rd_bias);
+                      float* top, float* qw, hipStream_t s, const float* rd_bias, void* ws = nullptr, size_t ws_bytes = 0);
+int set_matrix_mode(int mode);
+int get_matrix_mode();
 int embed_simcross_forward(int mode, int N, int W1, int W2, int D, int K, const float* index_q,
                            const float* index_a, const float* weight, const float* embed_bias, float* top,
                            float* norm0, float* norm1, hipStream_t s);
@@ -330,6 +332,18 @@ int mms_simmatrix_forward_f32(int N, int K1, int K2, const float* q, const float
   if (!q || !a || !W || !top || !qw_scratch) return MMS_ERR_INVALID_ARG;
   return simmatrix_forward(N, K1, K2, q, a, W, top, qw_scratch, as_stream(stream), nullptr);
 }
+
+int mms_simmatrix_forward_ws_f32(int N, int K1, int K2, const float* q, const float* a, const float* W, float* top,
+                                 float* qw_scratch, void* workspace, size_t workspace_bytes, void* stream) {
+  if (N < 0 || K1 <= 0 || K2 <= 0) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q || !a || !W || !top || !qw_scratch) return MMS_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < simmatrix_workspace_bytes(N, K1, K2)) return MMS_ERR_WORKSPACE;
+  return simmatrix_forward(N, K1, K2, q, a, W, top, qw_scratch, as_stream(stream), nullptr, workspace, workspace_bytes);
+}
+
+int mms_set_matrix_mode(int mode) { return set_matrix_mode(mode); }
+int mms_get_matrix_mode(void) { return get_matrix_mode(); }
 
 int mms_simmatrix_backward_f32(int N, int K1, int K2, const float* q, const float* a,
                                const float* W, const float* top_diff, int param_propagate_down,

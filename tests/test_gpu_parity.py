@@ -533,8 +533,22 @@ def test_bilinear_fused_forward_without_bias_and_ragged_tiles(oracle, hiplib):
 # --------------------------------------------------------------------------- #
 # SimMatrix: 1e-5
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("shape", [(16, 300, 300), (5, 7, 3), (700, 64, 48), (1, 1, 1), (900, 50, 50), (130, 33, 18), (2100, 12, 300)])
-def test_simmatrix(shape, oracle, hiplib):
+@pytest.fixture(params=["bf16x3", "fp32"])
+def matrix_mode(request, hiplib):
+    """Both matrix pipes behind the learned-metric products (include/mms.h: mms_set_matrix_mode): the default -- exact
+    three-way bf16 splits on the bf16 pipe, taken for N >= 2048 by calls that own a workspace -- and fp32 MFMA."""
+    from mms_answer_selection_amd import capi
+    capi.set_matrix_mode(request.param)
+    yield request.param
+    capi.set_matrix_mode("bf16x3")
+
+
+# N >= 2048: the shapes the split-bf16 kernel takes (one and two column groups, ragged last row panel, K not a multiple
+# of the 16-deep k-step, a single k-step, the 8-column minimum of the side job, N and K at the kernel's 320 limit)
+@pytest.mark.parametrize("shape", [(16, 300, 300), (5, 7, 3), (700, 64, 48), (1, 1, 1), (900, 50, 50), (130, 33, 18), (2100, 12, 300),
+                                   (2125, 300, 300), (4096, 64, 160), (2500, 52, 304), (3000, 300, 8), (2333, 20, 36),
+                                   (2048, 320, 320), (2050, 16, 164), (2049, 33, 18)])
+def test_simmatrix(shape, matrix_mode, oracle, hiplib):
     from mms_answer_selection_amd import capi
     N, K1, K2 = shape
     r = rng(sum(shape) + 3)
@@ -575,6 +589,38 @@ def test_simmatrix(shape, oracle, hiplib):
     capi.simmatrix_backward(qd, ad, Wd, dTd, None, inplace, None, param_propagate_down=False,
                             propagate_down=(False, True), qw=inplace)
     assert_bitexact(host(inplace), host(ga), "da scaled in place")
+
+
+def test_simmatrix_matrix_pipes_agree_and_mode_errors(hiplib):
+    """The two pipes give the same product to fp32 rounding (both far inside 1e-5), the workspace-less entry point stays on
+    the fp32 pipe, a bad mode is refused, and the documented edge of the split (inf -> NaN) is what happens."""
+    from mms_answer_selection_amd import capi
+    N, K = 4096, 300
+    r = rng(77)
+    q = dev((r.standard_normal((N, K)) * 0.4).astype(np.float32))
+    a = dev((r.standard_normal((N, K)) * 0.4).astype(np.float32))
+    W = dev(r.uniform(-0.08, 0.08, (K, K)).astype(np.float32))
+    out = {}
+    for mode in ("bf16x3", "fp32"):
+        capi.set_matrix_mode(mode)
+        assert capi.get_matrix_mode() == mode
+        top, qw = nan_like((N, 1)), nan_like((N, K))
+        capi.simmatrix_forward(q, a, W, top, qw)
+        out[mode] = (host(top), host(qw))
+    capi.set_matrix_mode("bf16x3")
+    top0, qw0 = nan_like((N, 1)), nan_like((N, K))
+    capi.simmatrix_forward(q, a, W, top0, qw0, use_workspace=False)
+    assert_bitexact(host(qw0), out["fp32"][1], "no workspace: the fp32 pipe")
+    ref = host(q).astype(np.float64) @ host(W).astype(np.float64)
+    e3, e32 = np.abs(out["bf16x3"][1] - ref).max(), np.abs(out["fp32"][1] - ref).max()
+    assert e3 <= 2e-6 and e32 <= 2e-6, (e3, e32)
+    assert e3 <= 2.0 * e32 + 1e-7, "the split product is as accurate as the fp32 one: %g vs %g" % (e3, e32)
+    assert hiplib.mms_set_matrix_mode(2) == 1 and capi.get_matrix_mode() == "bf16x3"
+    qi = q.clone(); qi[5, 7] = float("inf")
+    top, qw = nan_like((N, 1)), nan_like((N, K))
+    capi.simmatrix_forward(qi, a, W, top, qw)
+    h = host(qw)
+    assert np.isnan(h[5]).all() and np.isfinite(np.delete(h, 5, axis=0)).all(), "an infinity poisons its own row only"
 
 
 # --------------------------------------------------------------------------- #
@@ -1055,8 +1101,8 @@ def test_properties_full_size(hiplib):
     assert_bitexact(host(gq3), 2 * host(gq), "backward is linear in top_diff")
 
 
-def test_cfg3_simmatrix_full_size_against_fp64(hiplib):
-    """BASELINE cfg 3 (16384 x 300 x 300): fp64 closed form on the GPU box's host."""
+def test_cfg3_simmatrix_full_size_against_fp64(matrix_mode, hiplib):
+    """BASELINE cfg 3 (16384 x 300 x 300): fp64 closed form on the GPU box's host, on either matrix pipe."""
     from mms_answer_selection_amd import capi
     N, K = 16384, 300
     r = rng(33)
