@@ -1066,19 +1066,33 @@ def other_configs(torch, capi):
 
     # the Layer's call sequence: Backward reuses the forward's Q.W for da (3 GEMMs executed per step)
     def cfg3():
-        capi.simmatrix_forward(q, a, W, top, scr)
+        capi.simmatrix_forward(q, a, W, top, scr, ws=ws)
         capi.simmatrix_backward(q, a, W, dT, dq, da, dW, ws=ws, qw=scr)
-    us = _graph_time(torch, cfg3, iters=16)
     flops = 2.0 * N * K * K + 2.0 * N * K + 6.0 * N * K * K        # the reference's 4 products
     done = 2.0 * N * K * K + 2.0 * N * K + 4.0 * N * K * K         # executed: Q.W once
+    # round 3: the three products run on the BF16 matrix pipe at fp32 accuracy (every fp32 operand = the exact sum of
+    # three bf16 values; six bf16 products per fp32 product, fp32 accumulate: csrc/bx3_gemm.h) -- the default -- next
+    # to the fp32-MFMA pipe of rounds 1-2 (mms_set_matrix_mode(1)).  Same 1e-5 parity tests on both.
+    us = _graph_time(torch, cfg3, iters=16)
+    bf16_done = 6.0 * 3 * 2.0 * N * 304 * 320                       # bf16 flop actually issued (padded tiles, 6 products)
     out["cfg3_simmatrix_16384x300x300_fwd_bwd"] = {
         "us_per_step": us, "pairs_per_s": N / (us * 1e-6), "TFLOPs": flops / us / 1e6,
         "frac_mfma_fp32_peak": flops / (us * 1e-6) / 157.3e12,
         "executed_TFLOPs": done / us / 1e6, "executed_frac_mfma_fp32_peak": done / (us * 1e-6) / 157.3e12,
-        "bound": "mfma", "dtype": "f32"}
+        "bf16_pipe_TFLOPs_issued": bf16_done / us / 1e6, "frac_mfma_bf16_dense_peak": bf16_done / (us * 1e-6) / 2.5e15,
+        "bound": "mfma (bf16 pipe, 6 bf16 products per fp32 product) / L2->LDS operand stream / HBM epilogue",
+        "dtype": "f32 (exact 3-way bf16 splits, fp32 accumulate)", "matrix_mode": capi.get_matrix_mode()}
+    capi.set_matrix_mode("fp32")
+    us = _graph_time(torch, cfg3, iters=16)
+    capi.set_matrix_mode("bf16x3")
+    out["cfg3_simmatrix_fp32_mfma_pipe"] = {
+        "us_per_step": us, "pairs_per_s": N / (us * 1e-6), "TFLOPs": flops / us / 1e6,
+        "frac_mfma_fp32_peak": flops / (us * 1e-6) / 157.3e12,
+        "executed_TFLOPs": done / us / 1e6, "executed_frac_mfma_fp32_peak": done / (us * 1e-6) / 157.3e12,
+        "bound": "mfma", "dtype": "f32", "matrix_mode": "fp32"}
 
     def cfg3_nocache():
-        capi.simmatrix_forward(q, a, W, top, scr)
+        capi.simmatrix_forward(q, a, W, top, scr, ws=ws)
         capi.simmatrix_backward(q, a, W, dT, dq, da, dW, ws=ws)
     us = _graph_time(torch, cfg3_nocache, iters=16)
     out["cfg3_simmatrix_recomputing_backward"] = {

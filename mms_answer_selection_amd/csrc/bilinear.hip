@@ -1558,7 +1558,11 @@ static SimMatrixWs simmatrix_ws(int N, int K1, int K2) {
   const int psplit = panel_pick_ksplit((K1 + 63) / 64, 1, N, &pchunk);   // the panel kernel's split (if it runs)
   w.u_off = 0;
   w.part_off = round_up((size_t)N * K2 * sizeof(float), 256);
-  w.wt_off = w.part_off + round_up((size_t)(psplit > w.ksplit ? psplit : w.ksplit) * K1 * K2 * sizeof(float), 256);
+  int tchunk = 0;
+  const int tsplit = bx3_tn_pick_chunks(N, bx3_tn_quads(K1, K2), &tchunk);      // the split-bf16 dW kernel's split (if it runs)
+  int slabs = psplit > w.ksplit ? psplit : w.ksplit;
+  if (tsplit > slabs) slabs = tsplit;
+  w.wt_off = w.part_off + round_up((size_t)slabs * K1 * K2 * sizeof(float), 256);
   w.img_off = w.wt_off + round_up((size_t)K1 * K2 * sizeof(float), 256);    // W^T for the dq product (fp32 MFMA mode)
   const size_t ia = bx3_image_bytes(K2, K1), ib = bx3_image_bytes(K1, K2);  // the split image of W (forward) or W^T (dq)
   w.total = w.img_off + round_up(ia > ib ? ia : ib, 256);
@@ -1632,7 +1636,20 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
     float* part = reinterpret_cast<float*>(base + lay.part_off);
     // dW += sum_i dT_i q_i a_i^T = Q^T (diag(dT) A)   (:73-80, accumulating)
     bool dw_done = false;
-    {
+    if (g_matrix_mode == 0 && bx3_rows_worth(N)) {
+      // on the bf16 pipe: both operands split on the fly (bx3_gemm.h, bx3_tn_kernel), slabs summed in chunk order
+      Bx3TnArgs t{};
+      t.M = K1; t.N = K2; t.K = N; t.A = q; t.lda = K1; t.B = a; t.ldb = K2; t.kscale = top_diff; t.C = part;
+      t.c_ks = (long long)K1 * K2;
+      t.nchunks = bx3_tn_pick_chunks(N, bx3_tn_quads(K1, K2), &t.kchunk);
+      if (bx3_tn_eligible(t)) {
+        bx3_tn_launch(t, s);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks((long long)K1 * K2)), dim3(256), 0, s, part, t.nchunks,
+                           (long long)K1 * K2, dW, 1);
+        dw_done = true;
+      }
+    }
+    if (!dw_done) {
       PanelArgs p = panel_args(K1, K2, N, q, K1, a, K2, part, K2);
       p.kscale = top_diff;                      // A(i, k = pair) = q_k[i] * dT_k
       p.ksplit = panel_pick_ksplit(p.row_blocks, 1, N, &p.kchunk);

@@ -38,6 +38,8 @@
 #ifndef MMS_BX3_GEMM_H_
 #define MMS_BX3_GEMM_H_
 
+#include <type_traits>
+
 #include "mms_common.h"
 #include "panel_gemm.h"
 
@@ -601,39 +603,58 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
       colp[u] = (isb ? p.B : p.A) + col;
       ld[u] = isb ? p.ldb : p.lda;
     }
-    float raw[5][8], ksc[8];
-    auto fetch = [&](int s) {
+    // two register stages: step s + 2 is requested BEFORE step s + 1 is split, a whole step ahead of its use
+    float raw[2][5][8], ksc[2][8];
+    const float one = 1.f;
+    const float* const ksp = p.kscale ? p.kscale : &one;      // (no scale: every lane reads the same 1.0f)
+    const int kstep = p.kscale ? 1 : 0;
+    auto fetch = [&](auto stage, int s) {
+      constexpr int R = decltype(stage)::value;
+#if defined(MMS_BX3TN_ABLATE) && MMS_BX3TN_ABLATE == 3
+      return;
+#endif
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
+        // (branch-free: a load under a per-lane condition becomes a divergent branch with its own wait)
         int n = n0 + 32 * s + 8 * g + j;
         const bool ok = n < nend;
         n = ok ? n : p.K - 1;
-        ksc[j] = ok ? (p.kscale ? p.kscale[n] : 1.f) : 0.f;   // pairs past the chunk's end add zero
+        const float kv = ksp[n * kstep];
+        ksc[R][j] = ok ? kv : 0.f;                              // pairs past the chunk's end add zero
 #pragma unroll
-        for (int u = 0; u < 5; ++u) raw[u][j] = colp[u][(long long)n * ld[u]];
+        for (int u = 0; u < 5; ++u) raw[R][u][j] = colp[u][(long long)n * ld[u]];
       }
     };
-    auto emit = [&](int buf) {
+    auto emit = [&](auto stage, int buf) {
+      constexpr int R = decltype(stage)::value;
+#if defined(MMS_BX3TN_ABLATE) && MMS_BX3TN_ABLATE == 1
+      return;
+#endif
 #pragma unroll
       for (int u = 0; u < 5; ++u) {
         const int t = w + 4 * u;
         float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = t >= 10 ? raw[u][j] * ksc[j] : raw[u][j];
+        for (int j = 0; j < 8; ++j) x[j] = t >= 10 ? raw[R][u][j] * ksc[R][j] : raw[R][u][j];
         const pg_v4f r0 = {x[0], x[1], x[2], x[3]}, r1 = {x[4], x[5], x[6], x[7]};
         const Bx3Frag f = bx3_split8(r0, r1);
         bx3_u4* o = reinterpret_cast<bx3_u4*>(tn_lds + buf * BX3TN_BUF + t * 3072) + lane;
         o[0] = __builtin_bit_cast(bx3_u4, f.h); o[64] = __builtin_bit_cast(bx3_u4, f.m); o[128] = __builtin_bit_cast(bx3_u4, f.l);
       }
     };
-    fetch(0);
-    emit(0);
-    if (steps > 1) fetch(1);
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+    fetch(S0{}, 0);
+    if (steps > 1) fetch(S1{}, 1);
+    emit(S0{}, 0);
+    // step s: request step s + 2 into stage s & 1 (split one step ago), then split stage (s + 1) & 1 into buffer (s + 1) & 1
     for (int s = 0; s < steps; ++s) {
-      __syncthreads();                                      // buffer s % 2 is complete; the other one is free
-      if (s + 1 < steps) {
-        emit((s + 1) & 1);
-        if (s + 2 < steps) fetch(s + 2);
+      __syncthreads();                                      // buffer s & 1 is complete; the other one is free
+      if (s & 1) {
+        if (s + 2 < steps) fetch(S1{}, s + 2);
+        if (s + 1 < steps) emit(S0{}, 0);
+      } else {
+        if (s + 2 < steps) fetch(S0{}, s + 2);
+        if (s + 1 < steps) emit(S1{}, 1);
       }
     }
     return;
@@ -649,6 +670,9 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
   for (int s = 0; s < steps; ++s) {
     __syncthreads();
     const bx3_u4* img = reinterpret_cast<const bx3_u4*>(tn_lds + (s & 1) * BX3TN_BUF) + lane;
+#if defined(MMS_BX3TN_ABLATE) && MMS_BX3TN_ABLATE == 2
+    continue;
+#endif
     bx3_h8 ah[5], am[5], al[5];
 #pragma unroll
     for (int a = 0; a < 5; ++a) {
