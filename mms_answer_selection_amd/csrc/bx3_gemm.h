@@ -552,7 +552,7 @@ struct Bx3TnArgs {
   int M, N, K;                           // C (M x N) = sum over k < K of A[k][i] * (kscale[k] * B[k][j])
   const float* A; long long lda;
   const float* B; long long ldb;
-  const float* kscale;                   // may be null
+  const float* kscale;                   // K values (required)
   float* C; long long c_ks;              // slab ks at C + ks * c_ks, row stride N
   int kchunk, nchunks;                   // pairs per chunk (a multiple of 32), chunks
 };
@@ -591,8 +591,10 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
     // ------------------------------ splitter waves ------------------------------
     const int w = wave - 4, c = lane & 15, g = lane >> 4;
     // tiles w, w + 4, ... of the 20: tile t < 10 is columns [i0 + 16 t, +16) of A, else [j0 + 16 (t - 10), +16) of B
-    const float* colp[5];
+    const float* xb[5];                 // the tile's operand (wave-uniform)
     long long ld[5];
+    unsigned offl[5];                   // the lane's BYTE offset inside a step's 32 rows: 8 g rows down, its column
+    int colc[5];
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
       const int t = w + 4 * u;
@@ -600,29 +602,45 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
       int col = isb ? j0 + 16 * (t - 10) + c : i0 + 16 * t + c;
       const int lim = isb ? p.N : p.M;
       col = col < lim ? col : lim - 1;                 // columns past the edge: a valid column's values (outputs never stored)
-      colp[u] = (isb ? p.B : p.A) + col;
+      xb[u] = isb ? p.B : p.A;
       ld[u] = isb ? p.ldb : p.lda;
+      colc[u] = col;
+      offl[u] = (unsigned)((8 * g * ld[u] + col) * 4);   // bytes
     }
     // two register stages: step s + 2 is requested BEFORE step s + 1 is split, a whole step ahead of its use
     float raw[2][5][8], ksc[2][8];
-    const float one = 1.f;
-    const float* const ksp = p.kscale ? p.kscale : &one;      // (no scale: every lane reads the same 1.0f)
-    const int kstep = p.kscale ? 1 : 0;
+    const float* const ksp = p.kscale;
+    constexpr int kstep = 1;
     auto fetch = [&](auto stage, int s) {
       constexpr int R = decltype(stage)::value;
 #if defined(MMS_BX3TN_ABLATE) && MMS_BX3TN_ABLATE == 3
       return;
 #endif
+      const int nb = __builtin_amdgcn_readfirstlane(n0 + 32 * s);   // wave-uniform by construction; said so, the row bases are scalar
+      if (nb + 32 <= nend) {
+        // a whole step: one 64-bit address per tile, then row to row by one add -- the splitters share the vector pipe
+        // with a compute wave's MFMAs, and a full address per load (64-bit multiply-adds) cost more than the split itself
+        const float* kp = ksp + (nb + 8 * g) * kstep;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ksc[R][j] = kp[j * kstep];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const float* pu = xb[u] + (long long)(nb + 8 * g) * ld[u] + colc[u];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { raw[R][u][j] = *pu; pu += ld[u]; }
+        }
+        return;
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         // (branch-free: a load under a per-lane condition becomes a divergent branch with its own wait)
-        int n = n0 + 32 * s + 8 * g + j;
+        int n = nb + 8 * g + j;
         const bool ok = n < nend;
         n = ok ? n : p.K - 1;
         const float kv = ksp[n * kstep];
         ksc[R][j] = ok ? kv : 0.f;                              // pairs past the chunk's end add zero
 #pragma unroll
-        for (int u = 0; u < 5; ++u) raw[R][u][j] = colp[u][(long long)n * ld[u]];
+        for (int u = 0; u < 5; ++u) raw[R][u][j] = xb[u][(long long)n * ld[u] + colc[u]];
       }
     };
     auto emit = [&](auto stage, int buf) {
@@ -708,8 +726,9 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
 }
 
 inline bool bx3_tn_eligible(const Bx3TnArgs& p) {
-  return p.M >= 1 && p.N >= 1 && p.M <= 2 * BX3TN_Q && p.N <= 2 * BX3TN_Q && p.K >= 1 && p.kchunk > 0 && (p.kchunk & 31) == 0 &&
-         (long long)p.K * p.lda < (1LL << 31) && (long long)p.K * p.ldb < (1LL << 31);
+  return p.kscale && p.M >= 1 && p.N >= 1 && p.M <= 2 * BX3TN_Q && p.N <= 2 * BX3TN_Q && p.K >= 1 && p.kchunk > 0 && (p.kchunk & 31) == 0 &&
+         (long long)p.K * p.lda < (1LL << 31) && (long long)p.K * p.ldb < (1LL << 31) && 32 * p.lda < (1LL << 28) &&
+         32 * p.ldb < (1LL << 28);
 }
 
 inline void bx3_tn_launch(const Bx3TnArgs& p, hipStream_t s) {
