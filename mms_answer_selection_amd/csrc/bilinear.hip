@@ -631,6 +631,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// SimMatrix backward on the bf16 pipe: the split-K reduction of dW and the operand image of W^T for the dq product are two
+// independent small launches in a row; here they are ONE -- workgroups [0, red_blocks) reduce, the rest split.
+__global__ __launch_bounds__(256) void splitk_reduce_split_kernel(const float* __restrict__ part, int splits, long long n,
+                                                                  float* __restrict__ out, int accumulate, int red_blocks,
+                                                                  const Bx3SplitArgs sp) {
+  if ((int)blockIdx.x < red_blocks) {
+    const long long stride = (long long)red_blocks * 256;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
+      const float s = ordered_slab_sum(part, n, e, splits, 0.f);
+      out[e] = accumulate ? out[e] + s : s;
+    }
+    return;
+  }
+  bx3_split_b_body(sp, ((int)blockIdx.x - red_blocks) * 256 + threadIdx.x, ((int)gridDim.x - red_blocks) * 256);
+}
+
 // SimMatrix backward: the split-K reduction of dW and the transpose of W (the dq product's k-major B operand) are
 // two independent ~5-us launches in a row; here they are ONE -- workgroups [0, red_blocks) reduce, the rest
 // transpose 32 x 32 tiles -- which takes a launch (1.6 us of floor + the shorter kernel) off a cfg 3 step.
@@ -1644,8 +1660,16 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
       t.nchunks = bx3_tn_pick_chunks(N, bx3_tn_quads(K1, K2), &t.kchunk);
       if (bx3_tn_eligible(t)) {
         bx3_tn_launch(t, s);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks((long long)K1 * K2)), dim3(256), 0, s, part, t.nchunks,
-                           (long long)K1 * K2, dW, 1);
+        const unsigned rb = ew_blocks((long long)K1 * K2);
+        if (dq_bx3) {                            // the image of W^T for the dq product rides in the reduction's launch
+          bx3_u4* img = reinterpret_cast<bx3_u4*>(static_cast<char*>(ws) + lay.img_off);
+          const Bx3SplitArgs sp = bx3_split_args(W, 1, K2, K2, K1, img);
+          hipLaunchKernelGGL(splitk_reduce_split_kernel, dim3(rb + bx3_split_blocks(sp)), dim3(256), 0, s, part, t.nchunks,
+                             (long long)K1 * K2, dW, 1, (int)rb, sp);
+          wt_done = true;
+        } else {
+          hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, part, t.nchunks, (long long)K1 * K2, dW, 1);
+        }
         dw_done = true;
       }
     }
@@ -1688,7 +1712,7 @@ int simmatrix_backward(int N, int K1, int K2, const float* q, const float* a, co
     // dq_j = dT_j * (W a_j)   (:88, NoTrans, beta 0): B(k, n) = W[n][k], split straight from W's rows
     bx3_u4* img = reinterpret_cast<bx3_u4*>(static_cast<char*>(ws) + lay.img_off);
     bq.img = img;
-    bx3_split_b(W, 1, K2, K2, K1, img, s);
+    if (!wt_done) bx3_split_b(W, 1, K2, K2, K1, img, s);
     bx3_launch(bq, s);
     da_done = bq.side_in != nullptr;
   } else if (pd0) {
@@ -1769,7 +1793,7 @@ int triplet_loss_from_terms(const float* terms, int N, float* loss, hipStream_t 
 int pairrank_hinge_mode();
 
 struct TripSimWs {
-  size_t b_off, terms_off, ones_off, wt_off, part_off, total;
+  size_t b_off, terms_off, ones_off, wt_off, part_off, img_off, total;
   int ksplit, kchunk;
 };
 static TripSimWs tripsim_ws(int N, int K1, int K2) {
@@ -1781,7 +1805,11 @@ static TripSimWs tripsim_ws(int N, int K1, int K2) {
   w.terms_off = take((size_t)N * sizeof(float));
   w.ones_off = take((size_t)N * sizeof(float));
   w.wt_off = take((size_t)K1 * K2 * sizeof(float));
-  w.part_off = take((size_t)(w.ksplit > 0 ? w.ksplit : 1) * K1 * K2 * sizeof(float));
+  int tchunk = 0;
+  const int tsplit = bx3_tn_pick_chunks(N, bx3_tn_quads(K1, K2), &tchunk);   // the bf16-pipe dW kernel's split (if it runs)
+  const int slabs = tsplit > w.ksplit ? tsplit : (w.ksplit > 0 ? w.ksplit : 1);
+  w.part_off = take((size_t)slabs * K1 * K2 * sizeof(float));
+  w.img_off = take(bx3_image_bytes(K1, K2));                                  // the split image of W^T (dq on the bf16 pipe)
   w.total = o;
   return w;
 }
@@ -1820,6 +1848,27 @@ int triplet_simmatrix_step(int N, int K1, int K2, float margin, float loss_weigh
   if (loss) {
     const int rc = triplet_loss_from_terms(terms, N, loss, s);
     if (rc != MMS_OK) return rc;
+  }
+  // The two backward products on the bf16 pipe (matrix mode 0; bx3_gemm.h): dW += Q^T B from both operands split on the
+  // fly, dq = B W^T with the image of W^T built in the reduction's launch.  (The forward stays on the fp32 pipe: its
+  // epilogue needs whole rows of Q W in one workgroup, the bf16 kernel's workgroups own half a row each.)
+  if (g_matrix_mode == 0 && bx3_rows_worth(N)) {
+    Bx3TnArgs t{};
+    t.M = K1; t.N = K2; t.K = N; t.A = q; t.lda = K1; t.B = B; t.ldb = K2; t.kscale = ones; t.C = part;
+    t.c_ks = (long long)K1 * K2;
+    t.nchunks = bx3_tn_pick_chunks(N, bx3_tn_quads(K1, K2), &t.kchunk);
+    Bx3Args bq{};
+    bq.M = N; bq.N = K1; bq.K = K2; bq.A = B; bq.lda = K2; bq.C = dq; bq.ldc = K1; bq.stream_c = 1;
+    bq.img = reinterpret_cast<bx3_u4*>(base + lay.img_off);
+    if (bx3_tn_eligible(t) && bx3_eligible(bq)) {
+      bx3_tn_launch(t, s);
+      const unsigned rb = ew_blocks((long long)K1 * K2);
+      const Bx3SplitArgs sp = bx3_split_args(W, 1, K2, K2, K1, const_cast<bx3_u4*>(bq.img));
+      hipLaunchKernelGGL(splitk_reduce_split_kernel, dim3(rb + bx3_split_blocks(sp)), dim3(256), 0, s, part, t.nchunks,
+                         (long long)K1 * K2, dW, 1, (int)rb, sp);
+      bx3_launch(bq, s);
+      return launch_status();
+    }
   }
   panel_launch(p3, false, s);
   {

@@ -113,21 +113,29 @@ __device__ __forceinline__ Bx3Frag bx3_split8(const pg_v4f r0, const pg_v4f r1) 
 
 // B(k, n) = B[k*b_k + n*b_n]  ->  image [k-step][column tile][plane][lane]; one thread per (k-step, column tile, lane).
 // Rider: zero[0 .. zero_n) = 0 (the row-dot output two column groups add into).
-__global__ __launch_bounds__(256) void bx3_split_b_kernel(const float* __restrict__ B, long long b_k, long long b_n,
-                                                          int K, int N, int ksteps, int ntc, bx3_u4* __restrict__ img,
-                                                          float* __restrict__ zero, long long zero_stride, int zero_n) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  for (int z = idx; z < zero_n; z += gridDim.x * 256) zero[(long long)z * zero_stride] = 0.f;
-  if (idx >= ksteps * ntc * 64) return;
-  const int lane = idx & 63, t = (idx >> 6) % ntc, s = (idx >> 6) / ntc;
+struct Bx3SplitArgs {
+  const float* B; long long b_k, b_n; int K, N, ksteps, ntc; bx3_u4* img;
+  float* zero; long long zero_stride; int zero_n;
+};
+__device__ __forceinline__ void bx3_split_b_body(const Bx3SplitArgs& a, int idx, int nthreads) {
+  for (int z = idx; z < a.zero_n; z += nthreads) a.zero[(long long)z * a.zero_stride] = 0.f;
+  if (idx >= a.ksteps * a.ntc * 64) return;
+  const int lane = idx & 63, t = (idx >> 6) % a.ntc, s = (idx >> 6) / a.ntc;
   const int col = 32 * t + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
   float x[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = (col < N && k0 + j < K) ? B[(long long)(k0 + j) * b_k + (long long)col * b_n] : 0.f;
+  for (int j = 0; j < 8; ++j) {       // (clamped address + select: no divergent branch around the load)
+    const bool ok = col < a.N && k0 + j < a.K;
+    const float v = a.B[(long long)(ok ? k0 + j : 0) * a.b_k + (long long)(ok ? col : 0) * a.b_n];
+    x[j] = ok ? v : 0.f;
+  }
   const pg_v4f r0 = {x[0], x[1], x[2], x[3]}, r1 = {x[4], x[5], x[6], x[7]};
   const Bx3Frag f = bx3_split8(r0, r1);
-  bx3_u4* o = img + ((size_t)(s * ntc + t) * 3) * 64 + lane;
+  bx3_u4* o = a.img + ((size_t)(s * a.ntc + t) * 3) * 64 + lane;
   o[0] = __builtin_bit_cast(bx3_u4, f.h); o[64] = __builtin_bit_cast(bx3_u4, f.m); o[128] = __builtin_bit_cast(bx3_u4, f.l);
+}
+__global__ __launch_bounds__(256) void bx3_split_b_kernel(const Bx3SplitArgs a) {
+  bx3_split_b_body(a, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 #ifdef MMS_BX3_STAMPS     // dev-only (tools/bx3bench.hip): per-workgroup wall-clock (100 MHz) / shader-clock stamps of wave 0
@@ -503,11 +511,18 @@ inline bool bx3_eligible(const Bx3Args& p) {
 }
 
 // zero / zero_stride / zero_n: the row-dot output of a two-group product (null / 0 otherwise)
+inline Bx3SplitArgs bx3_split_args(const float* B, long long b_k, long long b_n, int K, int N, bx3_u4* img,
+                                   float* zero = nullptr, long long zero_stride = 1, int zero_n = 0) {
+  Bx3SplitArgs a{};
+  a.B = B; a.b_k = b_k; a.b_n = b_n; a.K = K; a.N = N; a.ksteps = bx3_ksteps(K); a.ntc = bx3_groups(N) * bx3_ntw(N); a.img = img;
+  a.zero = zero; a.zero_stride = zero_stride; a.zero_n = zero ? zero_n : 0;
+  return a;
+}
+inline unsigned bx3_split_blocks(const Bx3SplitArgs& a) { return (unsigned)((a.ksteps * a.ntc * 64 + 255) / 256); }
 inline void bx3_split_b(const float* B, long long b_k, long long b_n, int K, int N, bx3_u4* img, hipStream_t s,
                         float* zero = nullptr, long long zero_stride = 1, int zero_n = 0) {
-  const int ks = bx3_ksteps(K), ntc = bx3_groups(N) * bx3_ntw(N);
-  hipLaunchKernelGGL(bx3_split_b_kernel, dim3((unsigned)((ks * ntc * 64 + 255) / 256)), dim3(256), 0, s, B, b_k, b_n, K, N,
-                     ks, ntc, img, zero, zero_stride, zero ? zero_n : 0);
+  const Bx3SplitArgs a = bx3_split_args(B, b_k, b_n, K, N, img, zero, zero_stride, zero_n);
+  hipLaunchKernelGGL(bx3_split_b_kernel, dim3(bx3_split_blocks(a)), dim3(256), 0, s, a);
 }
 
 template <int NTW>

@@ -7,10 +7,16 @@ namespace caffe {
 
 template <>
 void SimMatrixLayer<float>::Forward_gpu(const vector<Blob<float>*>& bottom, const vector<Blob<float>*>& top) {
-  // Q*W lands in bottom[1]'s diff, where the reference's forward puts it (sim_matrix_layer.cpp:58)
-  const int rc = mms_simmatrix_forward_f32(M_, K1_, K2_, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
-                                           this->blobs_[0]->gpu_data(), top[0]->mutable_gpu_data(),
-                                           bottom[1]->mutable_gpu_diff(), /*stream=*/NULL);
+  // Q*W lands in bottom[1]'s diff, where the reference's forward puts it (sim_matrix_layer.cpp:58).
+  // With the layer's workspace (mms_simmatrix_workspace_bytes, the backward's) the product runs on the bf16 matrix
+  // pipe at fp32 accuracy for >= 2048 rows (include/mms.h); mms_simmatrix_forward_f32 (no workspace) stays on fp32 MFMA.
+  const size_t ws_bytes = mms_simmatrix_workspace_bytes(M_, K1_, K2_);
+  const int elems = (int)((ws_bytes + sizeof(float) - 1) / sizeof(float));
+  if (workspace_.count() < elems) workspace_.Reshape(vector<int>(1, elems));
+  const int rc = mms_simmatrix_forward_ws_f32(M_, K1_, K2_, bottom[0]->gpu_data(), bottom[1]->gpu_data(),
+                                              this->blobs_[0]->gpu_data(), top[0]->mutable_gpu_data(),
+                                              bottom[1]->mutable_gpu_diff(), workspace_.mutable_gpu_data(), ws_bytes,
+                                              /*stream=*/NULL);
   CHECK_EQ(rc, (int)MMS_OK) << mms_error_string(rc);
 }
 

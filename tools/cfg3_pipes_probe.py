@@ -28,6 +28,11 @@ dT = torch.randn(N, 1, device="cuda", generator=g)
 top, scr = torch.empty(N, 1, device="cuda"), torch.empty(N, K, device="cuda")
 dq, da, dW = torch.empty_like(q), torch.empty_like(a), torch.zeros_like(W)
 ws = capi.Workspace()
+an = torch.randn(N, K, device="cuda", generator=g) * 0.4
+yl = (torch.rand(N, 1, device="cuda", generator=g) < 0.8).float()
+sp, sn, ls = torch.empty(N, 1, device="cuda"), torch.empty(N, 1, device="cuda"), torch.empty(1, device="cuda")
+dan = torch.empty_like(a)
+ws2 = capi.Workspace()
 for mode in ("bf16x3", "fp32", "bf16x3"):
     capi.set_matrix_mode(mode)
     fwd = lambda: capi.simmatrix_forward(q, a, W, top, scr, ws=ws)
@@ -35,6 +40,7 @@ for mode in ("bf16x3", "fp32", "bf16x3"):
     dwo = lambda: capi.simmatrix_backward(q, a, W, dT, None, None, dW, ws=ws, propagate_down=(False, False))
     dqo = lambda: capi.simmatrix_backward(q, a, W, dT, dq, da, None, ws=ws, qw=scr, param_propagate_down=False)
     both = lambda: (fwd(), bwd())
-    print("%-7s fwd %.2f  bwd %.2f (dW only %.2f, dq+da only %.2f)  step %.2f us" % (
-        mode, gtime(fwd), gtime(bwd), gtime(dwo), gtime(dqo), gtime(both)), flush=True)
+    trip = lambda: capi.triplet_simmatrix_step(q, a, an, yl, W, sp, sn, ls, dq, da, dan, dW, margin=0.3, ws=ws2)
+    print("%-7s fwd %.2f  bwd %.2f (dW only %.2f, dq+da only %.2f)  step %.2f us   fused triplet step %.2f us" % (
+        mode, gtime(fwd), gtime(bwd), gtime(dwo), gtime(dqo), gtime(both), gtime(trip)), flush=True)
 capi.set_matrix_mode("bf16x3")
