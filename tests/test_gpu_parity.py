@@ -448,6 +448,8 @@ def test_cosine_forward_backward(shape, oracle, hiplib):
 @pytest.mark.parametrize("cfg", [
     (8, 1, 1, 300, 1, False),
     (2000, 1, 1, 300, 1, True),   # cfg 3 written as a SimCross layer: routed to SimMatrix's panel-GEMM launches
+    (2304, 1, 1, 300, 1, True),   # ... and, from 2048 pairs, to the bf16-pipe products (the bias rides in one column group's half)
+    (2100, 1, 1, 64, 1, False),   # ... one column group
     (777, 1, 1, 52, 1, True),
     (130, 1, 1, 301, 1, False),   # ... and its generic fallback (odd width)
     (4, 5, 7, 300, 2, True),
