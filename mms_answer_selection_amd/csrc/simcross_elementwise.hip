@@ -696,6 +696,93 @@ __global__ __launch_bounds__(256) void euclid_rows_wave_f16_kernel(
   }
 }
 
+// The ORDERED distance at large D without speculation (round 3; D > 400, where the kernel above runs one pair per wave
+// and its quad-shared speculative chain is 55 % of the launch: 18.9 us at cfg 5's shard).  One wave per pair loads,
+// squares and later differentiates its pair exactly as above; the squares go to LDS as the pair's image, and after one
+// workgroup barrier LANE p of wave 0 walks pair p's image front to back -- the reference's d-ascending fp32 sum
+// (sim_cross_layer.cpp:100-106) as 4 D4 dependent adds fed by D4 ds_read_b128, about 2.4 us for D = 1024 whatever the
+// number of lanes walking.  Eight pairs per workgroup, several workgroups per CU: one workgroup's walk hides behind the
+// others' loads and stores (the launch is HBM-bound: 67 MB).  No windows, no misses, no re-walks; bit-identical by
+// construction.
+template <int NIT, bool BWD, int WPB = 8>
+__global__ __launch_bounds__(64 * WPB) void euclid_rows_lanechain_f16_kernel(
+    const _Float16* __restrict__ q, const _Float16* __restrict__ a, const float* __restrict__ top_diff,
+    float* __restrict__ top_out, _Float16* __restrict__ dq, _Float16* __restrict__ da, int N, int D8) {
+  extern __shared__ float4 lc_lds[];             // [WPB pairs][D4 + 1] float4, then WPB floats (the distances)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * WPB + wave;
+  const int rowc = row < N ? row : N - 1;        // a missing pair mirrors the last one (results unused)
+  const int D4 = 2 * D8, st4 = D4 + 1;
+  const half8* q8 = reinterpret_cast<const half8*>(q) + (size_t)rowc * D8;
+  const half8* a8 = reinterpret_cast<const half8*>(a) + (size_t)rowc * D8;
+  float4* img = lc_lds + (size_t)wave * st4;
+  float* dist_lds = reinterpret_cast<float*>(lc_lds + (size_t)WPB * st4);
+
+  half8 x[NIT], y[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane + 64 * it, ii = i < D8 ? i : 0;
+    x[it] = q8[ii];
+    y[it] = a8[ii];
+  }
+  float g = 0.f;
+  if (BWD) g = top_diff[rowc];
+  float4 df[2 * NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane + 64 * it;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      float4 d;
+      d.x = (float)x[it][4 * hh + 0] - (float)y[it][4 * hh + 0];
+      d.y = (float)x[it][4 * hh + 1] - (float)y[it][4 * hh + 1];
+      d.z = (float)x[it][4 * hh + 2] - (float)y[it][4 * hh + 2];
+      d.w = (float)x[it][4 * hh + 3] - (float)y[it][4 * hh + 3];
+      df[2 * it + hh] = d;
+      float4 sq;
+      sq.x = d.x * d.x; sq.y = d.y * d.y; sq.z = d.z * d.z; sq.w = d.w * d.w;
+      if (i < D8) img[2 * i + hh] = sq;
+    }
+  }
+  __syncthreads();
+  if (wave == 0 && lane < WPB) {
+    const float4* mine = lc_lds + (size_t)lane * st4;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int i4 = 0; i4 < D4; ++i4) {
+      const float4 v = mine[i4];
+      acc += v.x; acc += v.y; acc += v.z; acc += v.w;
+    }
+    dist_lds[lane] = acc;
+  }
+  __syncthreads();
+  if (row >= N) return;
+  const float dist = dist_lds[wave];
+  const float T = 1.0f / (1.0f + sqrtf(dist));
+  if (BWD) asm volatile("" : "+v"(g));          // in a register before the store of T (see euclid_pair32_kernel)
+  if (lane == 0) top_out[row] = T;
+  if (!BWD) return;
+  const EuclidCoef k = euclid_coef(T, g);
+  half8* dq8 = reinterpret_cast<half8*>(dq) + (size_t)row * D8;
+  half8* da8 = reinterpret_cast<half8*>(da) + (size_t)row * D8;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = lane + 64 * it;
+    if (i >= D8) break;
+    half8 o0, o1;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const float4 t = euclid_tt4(k, df[2 * it + hh]);
+      o0[4 * hh + 0] = (_Float16)(0.f + t.x); o0[4 * hh + 1] = (_Float16)(0.f + t.y);
+      o0[4 * hh + 2] = (_Float16)(0.f + t.z); o0[4 * hh + 3] = (_Float16)(0.f + t.w);
+      o1[4 * hh + 0] = (_Float16)(0.f + (-t.x)); o1[4 * hh + 1] = (_Float16)(0.f + (-t.y));
+      o1[4 * hh + 2] = (_Float16)(0.f + (-t.z)); o1[4 * hh + 3] = (_Float16)(0.f + (-t.w));
+    }
+    stream_store_vec(dq8 + i, o0);
+    stream_store_vec(da8 + i, o1);
+  }
+}
+
 // fp16-STORAGE cosine, W1 = W2 = 1 (round 3; cfg 5's "multi-modal concat embeddings, fp16" with dist_mode 0): one
 // wave per pair, a lane holds NIT half8 of q and of a (all 16-byte loads up front, kept for the backward), fp32
 // arithmetic on the exactly-widened inputs: three tree sums (the reference's cblas_sdot has no defined order), the
@@ -798,8 +885,10 @@ int simcross_euclid_rows_f16(int N, int D, const void* q, const void* a, const f
   const int nit = (rw * D8 + 63) / 64;
   const unsigned grid = (unsigned)((N + 4 * rw - 1) / (4 * rw));
   // one pair per wave: the quad-shared chain (MMS_F16_CHAIN=lanes selects the per-lane chain, for A/B timing)
-  static const bool quad_off = [] { const char* e = std::getenv("MMS_F16_CHAIN"); return e && !std::strcmp(e, "lanes"); }();
+  static const bool quad_off = [] { const char* e = std::getenv("MMS_F16_CHAIN"); return e && !std::strcmp(e, "lanes"); }();   // "quad": the quad chain
   const bool quad = rw == 1 && !quad_off;
+  static const bool chain_env = [] { return std::getenv("MMS_F16_CHAIN") != nullptr; }();
+  const bool chain_old = rw == 2 || chain_env;      // (rw == 2 is handled above this branch)
   const bool tree = f16_distance_mode() == MMS_F16_DISTANCE_TREE;
   const size_t lds = (size_t)4 * rw * 3 * (quad ? quad_h4(2 * D8) : (2 * D8 + 2) / 3) * sizeof(float4);
   const _Float16* qh = static_cast<const _Float16*>(q);
@@ -842,6 +931,42 @@ int simcross_euclid_rows_f16(int N, int D, const void* q, const void* a, const f
       case 3: MMS_F16_LAUNCH(3, 2); break;
       default: MMS_F16_LAUNCH(4, 2); break;
     }
+  } else if (!chain_old) {
+    // D > 400, ordered: lane p of wave 0 walks pair p's image (MMS_F16_CHAIN=quad / lanes select round 2's speculative
+    // chains, for A/B timing)
+    static const int wpb = [] { const char* e = std::getenv("MMS_F16_LC_WPB"); const int v = e ? std::atoi(e) : 8;
+                                return v == 4 || v == 16 ? v : 8; }();        // dev-only A/B of the workgroup size
+    const unsigned gridw = (unsigned)((N + wpb - 1) / wpb);
+    const size_t ldsw = ((size_t)wpb * (2 * D8 + 1) + 4) * sizeof(float4);
+#define MMS_F16_LCW(n, w)                                                                             \
+  do {                                                                                                \
+    static bool once = [] {                                                                           \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&euclid_rows_lanechain_f16_kernel<n, true, w>),  \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&euclid_rows_lanechain_f16_kernel<n, false, w>), \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+      return true;                                                                                    \
+    }();                                                                                              \
+    (void)once;                                                                                       \
+    if (bwd)                                                                                          \
+      hipLaunchKernelGGL((euclid_rows_lanechain_f16_kernel<n, true, w>), dim3(gridw), dim3(64 * w), ldsw, \
+                         s, qh, ah, top_diff, top, dqh, dah, N, D8);                                  \
+    else                                                                                              \
+      hipLaunchKernelGGL((euclid_rows_lanechain_f16_kernel<n, false, w>), dim3(gridw), dim3(64 * w), ldsw, \
+                         s, qh, ah, top_diff, top, dqh, dah, N, D8);                                  \
+  } while (0)
+#define MMS_F16_LC(n)                                                                                 \
+  do {                                                                                                \
+    if (wpb == 4) MMS_F16_LCW(n, 4); else if (wpb == 16) MMS_F16_LCW(n, 16); else MMS_F16_LCW(n, 8);  \
+  } while (0)
+    switch (nit) {
+      case 1: MMS_F16_LC(1); break;
+      case 2: MMS_F16_LC(2); break;
+      case 3: MMS_F16_LC(3); break;
+      default: MMS_F16_LC(4); break;
+    }
+#undef MMS_F16_LCW
+#undef MMS_F16_LC
   } else if (!quad) {
     switch (nit) {
       case 1: MMS_F16_LAUNCH(1, 1); break;

@@ -33,5 +33,5 @@ for ring in (1, 12):
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3 / 48)
     ts.sort()
-    print("f16 %d x %d chain=%s %s: median %.2f us  min %.2f" % (N, D, "tree-sum" if os.environ.get("MMS_F16_TREE") == "1" else os.environ.get("MMS_F16_CHAIN", "quad"),
+    print("f16 %d x %d chain=%s %s: median %.2f us  min %.2f" % (N, D, "tree-sum" if os.environ.get("MMS_F16_TREE") == "1" else os.environ.get("MMS_F16_CHAIN", "lane-walk (default)"),
           "warm" if ring == 1 else "cold", ts[len(ts) // 2], ts[0]))
