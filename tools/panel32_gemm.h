@@ -1,4 +1,4 @@
-// csrc/panel32_gemm.h -- round 3: the panel fp32-MFMA GEMM re-cut for TWO co-resident workgroups per CU.
+// tools/panel32_gemm.h -- round 3 EXPERIMENT (not part of the product; kept for tools/panel32bench.hip): the panel fp32-MFMA GEMM re-cut for TWO co-resident workgroups per CU.
 //
 //   C[M x N] = A[M x K] . B[K x N]      (same PanelArgs, same semantics and k order class as panel_gemm.h)
 //

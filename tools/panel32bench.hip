@@ -1,7 +1,7 @@
-// tools/panel32bench.hip -- dev harness (not product): the 32-row panel GEMM (csrc/panel32_gemm.h) checked against
+// tools/panel32bench.hip -- dev harness (not product): the 32-row panel GEMM (tools/panel32_gemm.h) checked against
 // an fp64 product on the device and timed next to round 2's 64-row kernel, on cfg 3's three products
 // (SimMatrix 16384 x 300 x 300).  Build + run on the GPU box:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I mms_answer_selection_amd/csrc \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I mms_answer_selection_amd/csrc -I tools \
 //         tools/panel32bench.hip -o /tmp/panel32bench && /tmp/panel32bench [N]
 #include <hip/hip_runtime.h>
 #include <cstdio>
