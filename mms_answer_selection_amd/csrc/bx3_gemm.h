@@ -11,7 +11,8 @@
 // < 2^-22, fp32 accumulate in the MFMA.  Six v_mfma_f32_32x32x16_bf16 do the work of sixteen fp32 16x16x4 steps in
 // 6/16 of the pipe time; results agree with an fp32 BLAS product inside these layers' 1e-5 contract (the reference
 // calls cblas_sgemm, no defined order) -- tests/test_gpu_parity.py holds them to fp64.  Inputs holding an infinity
-// come out as NaN (inf - inf in the split), where an fp32 product gives inf or NaN.
+// come out as NaN (inf - inf in the split), where an fp32 product gives inf or NaN; so do magnitudes above bf16's largest
+// finite value (3.39e38: the first plane rounds to infinity).
 //
 // Shape of a launch:
 //   * the weight B is split ONCE per call by bx3_split_b_kernel into an operand IMAGE: for k-step s (16 deep), column
