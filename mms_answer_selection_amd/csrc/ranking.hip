@@ -414,44 +414,100 @@ __global__ __launch_bounds__(1024) void rank_mid_kernel(int n, int stride, int o
 #ifdef MMS_RANK_STAMPS
   st1 = __builtin_amdgcn_s_memrealtime();
 #endif
-  int buf = 0;
-  for (int kk = 2; kk <= kRankMid; kk <<= 1) {
+  // Sort = (1) each wave sorts its 128 items in registers (bitonic network of 28 passes; the partner of a lane at
+  // distance 1 / 2 / 4 / 8 / 16 / 32 comes by DPP or v_permlane{16,32}_swap, no LDS), then (2) four MERGE rounds
+  // 128 -> 256 -> 512 -> 1024 -> 2048: every item finds by binary search how many items of the sibling run precede it
+  // ((key, index) pairs are distinct, so "precede" needs no tie rule) and is written to its merged position in the other
+  // LDS buffer.  8 + 9 + 10 + 11 dependent LDS reads and four barriers instead of the 66 passes (56 of them 6
+  // ds_bpermute each, 10 through LDS with a barrier) of one flat bitonic network: 19 -> 11.8 us at 1,517 items on a lone
+  // workgroup (stamps, tools/rank_mid_probe.py: the 38 search steps are bound by the LDS round trip at that clock).
+  const int lane_s = t & 63;
+  auto lane_xor = [&](unsigned x, int m) -> unsigned {          // the value lane (lane ^ m) holds
+    switch (m) {
+      case 1: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+      case 2: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+      case 4: {
+        const unsigned up = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0xf, true);   // row_shl:4: lane i <- i + 4
+        const unsigned dn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   // row_shr:4: lane i <- i - 4
+        return (lane_s & 4) ? dn : up;
+      }
+      case 8: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true);     // row_ror:8 (= xor 8 in a row of 16)
+      case 16: { const auto sw = __builtin_amdgcn_permlane16_swap(x, x, false, false); return sw[0] ^ sw[1] ^ x; }
+      default: { const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false); return sw[0] ^ sw[1] ^ x; }
+    }
+  };
+#pragma unroll
+  for (int kk = 2; kk <= 128; kk <<= 1) {
+#pragma unroll
     for (int j = kk >> 1; j > 0; j >>= 1) {
-      if (j == 1) {                                   // positions 2t and 2t + 1: inside the thread
-        const bool up = ((2 * t) & kk) == 0;
+      if (j == 1) {                                   // local positions 2 lane and 2 lane + 1: inside the thread
+        const bool up = ((2 * lane_s) & kk) == 0;
         const bool gt = k[0] > k[1] || (k[0] == k[1] && v[0] > v[1]);
         if (gt == up) {
           const unsigned long long tk = k[0]; k[0] = k[1]; k[1] = tk;
           const unsigned tv = v[0]; v[0] = v[1]; v[1] = tv;
         }
-      } else if (j <= 64) {                           // partner thread t ^ (j / 2), same wave: shuffles
+      } else {
         const int m = j >> 1;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const int p = 2 * t + e;
-          const unsigned lo = __shfl_xor((unsigned)k[e], m, 64), hi = __shfl_xor((unsigned)(k[e] >> 32), m, 64);
-          const unsigned vo = __shfl_xor(v[e], m, 64);
+          const int p = 2 * lane_s + e;               // position inside the wave's block of 128
+          const unsigned lo = lane_xor((unsigned)k[e], m), hi = lane_xor((unsigned)(k[e] >> 32), m);
+          const unsigned vo = lane_xor(v[e], m);
           const unsigned long long ko = ((unsigned long long)hi << 32) | lo;
           const bool lower = (p & j) == 0, up = (p & kk) == 0;
           if (!keep_mine(k[e], v[e], ko, vo, lower, up)) { k[e] = ko; v[e] = vo; }
         }
-      } else {                                        // another wave: through LDS, one barrier per pass
-        unsigned long long* bk = buf ? xk : keys;
-        unsigned* bv = buf ? xv : vals;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) { bk[2 * t + e] = k[e]; bv[2 * t + e] = v[e]; }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int p = 2 * t + e, q = p ^ j;
-          const unsigned long long ko = bk[q];
-          const unsigned vo = bv[q];
-          const bool lower = (p & j) == 0, up = (p & kk) == 0;
-          if (!keep_mine(k[e], v[e], ko, vo, lower, up)) { k[e] = ko; v[e] = vo; }
-        }
-        buf ^= 1;                                     // the next LDS pass writes the other buffer: this one may still be read
       }
     }
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) { keys[2 * t + e] = k[e]; vals[2 * t + e] = v[e]; }
+  int buf = 0;                                        // 0: the runs are in keys / vals, 1: in xk / xv
+#pragma unroll 1
+  for (int L = 128; L < kRankMid; L <<= 1) {
+    __syncthreads();
+    const unsigned long long* ck = buf ? xk : keys;
+    const unsigned* cv = buf ? xv : vals;
+    unsigned long long* nk = buf ? keys : xk;
+    unsigned* nv = buf ? vals : xv;
+    int cnt[2], sbase[2];
+    unsigned long long mk[2];
+    unsigned mv[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int pos = 2 * t + e;
+      mk[e] = ck[pos]; mv[e] = cv[pos];
+      sbase[e] = (pos & ~(L - 1)) ^ L;                // first position of the sibling run
+      cnt[e] = 0;
+    }
+    for (int sstep = L >> 1; sstep >= 1; sstep >>= 1) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int q = sbase[e] + cnt[e] + sstep - 1;
+        const unsigned long long ok = ck[q];
+        const unsigned ov = cv[q];
+        if (ok < mk[e] || (ok == mk[e] && ov < mv[e])) cnt[e] += sstep;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int q = sbase[e] + cnt[e];                // (cnt <= L - 1 here: one more look decides cnt == L)
+      const unsigned long long ok = ck[q];
+      const unsigned ov = cv[q];
+      if (ok < mk[e] || (ok == mk[e] && ov < mv[e])) cnt[e] += 1;
+      const int pos = 2 * t + e;
+      const int np = (pos & ~(2 * L - 1)) + (pos & (L - 1)) + cnt[e];
+      nk[np] = mk[e]; nv[np] = mv[e];
+    }
+    buf ^= 1;
+  }
+  __syncthreads();
+  {
+    const unsigned long long* ck = buf ? xk : keys;
+    const unsigned* cv = buf ? xv : vals;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { k[e] = ck[2 * t + e]; v[e] = cv[2 * t + e]; }
   }
   __syncthreads();                                    // the last readers of `keys` / `vals` as exchange buffers are done
 #ifdef MMS_RANK_STAMPS
