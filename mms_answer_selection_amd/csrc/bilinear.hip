@@ -1843,7 +1843,20 @@ int triplet_simmatrix_step(int N, int K1, int K2, float margin, float loss_weigh
   p3.ksplit = lay.ksplit; p3.kchunk = lay.kchunk; p3.c_ks = (long long)K1 * K2;
   if (!panel_eligible(p1, true) || !panel_eligible(p2, true) || p3.ksplit <= 1 || !panel_eligible(p3, false))
     return MMS_ERR_UNSUPPORTED;
-  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ones), 0x3f800000, (size_t)N, s) != hipSuccess) return MMS_ERR_LAUNCH;
+  // (the ones are the fp32 split-K kernel's k-scale; the bf16-pipe dW kernel takes "no scale" as such)
+  Bx3TnArgs t{};
+  Bx3Args bq{};
+  bool back_bx3 = false;
+  if (g_matrix_mode == 0 && bx3_rows_worth(N)) {
+    t.M = K1; t.N = K2; t.K = N; t.A = q; t.lda = K1; t.B = B; t.ldb = K2; t.kscale = nullptr; t.C = part;
+    t.c_ks = (long long)K1 * K2;
+    t.nchunks = bx3_tn_pick_chunks(N, bx3_tn_quads(K1, K2), &t.kchunk);
+    bq.M = N; bq.N = K1; bq.K = K2; bq.A = B; bq.lda = K2; bq.C = dq; bq.ldc = K1; bq.stream_c = 1;
+    bq.img = reinterpret_cast<bx3_u4*>(base + lay.img_off);
+    back_bx3 = bx3_tn_eligible(t) && bx3_eligible(bq);
+  }
+  if (!back_bx3 &&
+      hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ones), 0x3f800000, (size_t)N, s) != hipSuccess) return MMS_ERR_LAUNCH;
   panel_launch(p1, true, s);
   if (loss) {
     const int rc = triplet_loss_from_terms(terms, N, loss, s);
@@ -1852,23 +1865,14 @@ int triplet_simmatrix_step(int N, int K1, int K2, float margin, float loss_weigh
   // The two backward products on the bf16 pipe (matrix mode 0; bx3_gemm.h): dW += Q^T B from both operands split on the
   // fly, dq = B W^T with the image of W^T built in the reduction's launch.  (The forward stays on the fp32 pipe: its
   // epilogue needs whole rows of Q W in one workgroup, the bf16 kernel's workgroups own half a row each.)
-  if (g_matrix_mode == 0 && bx3_rows_worth(N)) {
-    Bx3TnArgs t{};
-    t.M = K1; t.N = K2; t.K = N; t.A = q; t.lda = K1; t.B = B; t.ldb = K2; t.kscale = ones; t.C = part;
-    t.c_ks = (long long)K1 * K2;
-    t.nchunks = bx3_tn_pick_chunks(N, bx3_tn_quads(K1, K2), &t.kchunk);
-    Bx3Args bq{};
-    bq.M = N; bq.N = K1; bq.K = K2; bq.A = B; bq.lda = K2; bq.C = dq; bq.ldc = K1; bq.stream_c = 1;
-    bq.img = reinterpret_cast<bx3_u4*>(base + lay.img_off);
-    if (bx3_tn_eligible(t) && bx3_eligible(bq)) {
-      bx3_tn_launch(t, s);
-      const unsigned rb = ew_blocks((long long)K1 * K2);
-      const Bx3SplitArgs sp = bx3_split_args(W, 1, K2, K2, K1, const_cast<bx3_u4*>(bq.img));
-      hipLaunchKernelGGL(splitk_reduce_split_kernel, dim3(rb + bx3_split_blocks(sp)), dim3(256), 0, s, part, t.nchunks,
-                         (long long)K1 * K2, dW, 1, (int)rb, sp);
-      bx3_launch(bq, s);
-      return launch_status();
-    }
+  if (back_bx3) {
+    bx3_tn_launch(t, s);
+    const unsigned rb = ew_blocks((long long)K1 * K2);
+    const Bx3SplitArgs sp = bx3_split_args(W, 1, K2, K2, K1, const_cast<bx3_u4*>(bq.img));
+    hipLaunchKernelGGL(splitk_reduce_split_kernel, dim3(rb + bx3_split_blocks(sp)), dim3(256), 0, s, part, t.nchunks,
+                       (long long)K1 * K2, dW, 1, (int)rb, sp);
+    bx3_launch(bq, s);
+    return launch_status();
   }
   panel_launch(p3, false, s);
   {

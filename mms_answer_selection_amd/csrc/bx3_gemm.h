@@ -568,7 +568,7 @@ struct Bx3TnArgs {
   int M, N, K;                           // C (M x N) = sum over k < K of A[k][i] * (kscale[k] * B[k][j])
   const float* A; long long lda;
   const float* B; long long ldb;
-  const float* kscale;                   // K values (required)
+  const float* kscale;                   // K values, or null
   float* C; long long c_ks;              // slab ks at C + ks * c_ks, row stride N
   int kchunk, nchunks;                   // pairs per chunk (a multiple of 32), chunks
 };
@@ -625,8 +625,7 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
     }
     // two register stages: step s + 2 is requested BEFORE step s + 1 is split, a whole step ahead of its use
     float raw[2][5][8], ksc[2][8];
-    const float* const ksp = p.kscale;
-    constexpr int kstep = 1;
+    const float* const ksp = p.kscale;                        // null: no scale
     auto fetch = [&](auto stage, int s) {
       constexpr int R = decltype(stage)::value;
 #if defined(MMS_BX3TN_ABLATE) && MMS_BX3TN_ABLATE == 3
@@ -636,9 +635,14 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
       if (nb + 32 <= nend) {
         // a whole step: one 64-bit address per tile, then row to row by one add -- the splitters share the vector pipe
         // with a compute wave's MFMAs, and a full address per load (64-bit multiply-adds) cost more than the split itself
-        const float* kp = ksp + (nb + 8 * g) * kstep;
+        if (ksp) {
+          const float* kp = ksp + (nb + 8 * g);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ksc[R][j] = kp[j * kstep];
+          for (int j = 0; j < 8; ++j) ksc[R][j] = kp[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ksc[R][j] = 1.f;
+        }
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
           const float* pu = xb[u] + (long long)(nb + 8 * g) * ld[u] + colc[u];
@@ -653,7 +657,7 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
         int n = nb + 8 * g + j;
         const bool ok = n < nend;
         n = ok ? n : p.K - 1;
-        const float kv = ksp[n * kstep];
+        const float kv = ksp ? ksp[n] : 1.f;                    // (wave-uniform choice: no divergent branch)
         ksc[R][j] = ok ? kv : 0.f;                              // pairs past the chunk's end add zero
 #pragma unroll
         for (int u = 0; u < 5; ++u) raw[R][u][j] = xb[u][(long long)n * ld[u] + colc[u]];
@@ -742,7 +746,7 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
 }
 
 inline bool bx3_tn_eligible(const Bx3TnArgs& p) {
-  return p.kscale && p.M >= 1 && p.N >= 1 && p.M <= 2 * BX3TN_Q && p.N <= 2 * BX3TN_Q && p.K >= 1 && p.kchunk > 0 && (p.kchunk & 31) == 0 &&
+  return p.M >= 1 && p.N >= 1 && p.M <= 2 * BX3TN_Q && p.N <= 2 * BX3TN_Q && p.K >= 1 && p.kchunk > 0 && (p.kchunk & 31) == 0 &&
          (long long)p.K * p.lda < (1LL << 31) && (long long)p.K * p.ldb < (1LL << 31) && 32 * p.lda < (1LL << 28) &&
          32 * p.ldb < (1LL << 28);
 }
