@@ -41,7 +41,7 @@ extern "C" {
 /* 0.2.0: mms_embed_simcross_forward_f32 gained `embed_bias`, mms_rank_workspace_bytes and the mms_layer_t option
  * table changed (round 2), the triplet workspace carries the arrival words and must be initialised (round 3).
  * A host built against another header must refuse to run: compare mms_version() with MMS_VERSION at start-up. */
-#define MMS_VERSION 210
+#define MMS_VERSION 211
 
 enum {
   MMS_OK = 0,
@@ -254,6 +254,16 @@ int mms_simmatrix_forward_ws_f32(int N, int K1, int K2, const float* q,
                                  size_t workspace_bytes, void* stream);
 int mms_set_matrix_mode(int mode);
 int mms_get_matrix_mode(void);
+
+/* fp16-STORAGE SimMatrix scoring (no reference instantiation: common.hpp:41-44; cfg 5's "fp16 embeddings" with a learned
+ * metric): q (N,K1) and a (N,K2) IEEE half in HBM, W (K1,K2) and top (N) fp32; top_i = a_i . (q_i W), the forward of
+ * sim_matrix_layer.cpp:53-65 without its Q*W output.  Runs on the bf16 matrix pipe whatever the matrix mode: a half is
+ * the exact sum of two bf16 values, so the products are formed exactly and accumulated in fp32 -- the fp32 layer's
+ * result on the widened inputs to fp32 rounding (1e-5).  K1 % 8 == 0 (any length), K2 % 4 == 0, K2 <= 320, q 16-byte and a
+ * 8-byte aligned, else MMS_ERR_UNSUPPORTED (there is no fp32 fallback).  workspace: mms_simmatrix_workspace_bytes. */
+int mms_simmatrix_forward_f16(int N, int K1, int K2, const void* q_f16, const void* a_f16,
+                              const float* W, float* top, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* Replaces SimMatrixLayer<float>::Backward_cpu / Backward_gpu
  *   src/caffe/layers/sim_matrix_layer.cpp:68-95, sim_matrix_layer.cu:43-46.

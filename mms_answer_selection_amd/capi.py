@@ -30,6 +30,7 @@ _SIGNATURES = {
     "mms_embed_simcross_bilinear_forward_f32": (_i, [_i] * 6 + [_vp] * 8),
     "mms_simmatrix_forward_f32": (_i, [_i] * 3 + [_vp] * 6),
     "mms_simmatrix_forward_ws_f32": (_i, [_i] * 3 + [_vp] * 6 + [_sz, _vp]),
+    "mms_simmatrix_forward_f16": (_i, [_i] * 3 + [_vp] * 5 + [_sz, _vp]),
     "mms_set_matrix_mode": (_i, [_i]),
     "mms_get_matrix_mode": (_i, []),
     "mms_simmatrix_backward_f32": (_i, [_i] * 3 + [_vp] * 4 + [_i] * 3 + [_vp] * 4 + [_sz, _vp]),
@@ -93,7 +94,7 @@ class MMSError(RuntimeError):
     pass
 
 
-MMS_VERSION = 210      # include/mms.h
+MMS_VERSION = 211      # include/mms.h
 
 
 def lib():
@@ -245,6 +246,16 @@ def simmatrix_forward(q, a, W, top, qw_scratch, ws=None, use_workspace=True):
     check(lib().mms_simmatrix_forward_ws_f32(
         N, K1, K2, _ptr(q, "q"), _ptr(a, "a"), _ptr(W, "W"), _ptr(top, "top"),
         _ptr(qw_scratch, "qw_scratch"), wsp, wsb, _stream()), "mms_simmatrix_forward_ws_f32")
+
+
+def simmatrix_forward_f16(q, a, W, top, ws=None):
+    """fp16-storage scoring: q, a half tensors, W and top float32 (include/mms.h: mms_simmatrix_forward_f16)."""
+    N = q.shape[0]
+    K1, K2 = W.shape
+    h = torch.float16
+    wsp, wsb = (ws or _default_ws).get(lib().mms_simmatrix_workspace_bytes(N, K1, K2), q.device)
+    check(lib().mms_simmatrix_forward_f16(N, K1, K2, _ptr(q, "q", dtype=h), _ptr(a, "a", dtype=h), _ptr(W, "W"),
+                                          _ptr(top, "top"), wsp, wsb, _stream()), "mms_simmatrix_forward_f16")
 
 
 def set_matrix_mode(mode):

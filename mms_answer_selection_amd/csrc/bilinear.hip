@@ -1620,6 +1620,26 @@ int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, con
   return launch_status();
 }
 
+// fp16-STORAGE scoring (round 3): q (N, K1) and a (N, K2) are IEEE halves in HBM, W (K1, K2) and the scores fp32.
+// top_i = a_i . (q_i W) on the bf16 pipe: a half is the exact sum of two bf16 values, the weight of three, so five of
+// the six partial products exist and each is exact in fp32 -- the result is the fp32 layer's on the widened inputs
+// to fp32 rounding (1e-5 bar as everywhere BLAS-ordered).  No Q.W output: scoring does not need it.  No fp32 fallback:
+// shapes outside the kernel are MMS_ERR_UNSUPPORTED.
+int simmatrix_forward_f16(int N, int K1, int K2, const void* q, const void* a, const float* W, float* top, void* ws,
+                          size_t ws_bytes, hipStream_t s) {
+  const SimMatrixWs lay = simmatrix_ws(N, K1, K2);
+  if (!ws || ws_bytes < lay.total) return MMS_ERR_WORKSPACE;
+  Bx3Args b{};
+  b.M = N; b.N = K2; b.K = K1; b.A = static_cast<const float*>(q); b.lda = K1; b.a_half = 1;
+  b.Y = static_cast<const float*>(a); b.ldy = K2; b.rowdot = top; b.rd_stride = 1;
+  if (!bx3_eligible(b)) return MMS_ERR_UNSUPPORTED;
+  bx3_u4* img = reinterpret_cast<bx3_u4*>(static_cast<char*>(ws) + lay.img_off);
+  b.img = img;
+  bx3_split_b(W, K2, 1, K1, K2, img, s, bx3_groups(K2) == 2 ? top : nullptr, 1, N);
+  bx3_launch(b, s);
+  return launch_status();
+}
+
 // qw (optional): the forward's Q.W, unchanged since; may alias da.  da_j = dT_j * (W^T q_j) is row j of
 // Q.W scaled by dT_j -- the product the forward already made with the same kernel and k order, so
 // reusing it returns the same bits as recomputing it and saves one of the four GEMMs of a step.

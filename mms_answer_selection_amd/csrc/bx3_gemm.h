@@ -61,6 +61,7 @@ struct Bx3Args {
   const float* Y; long long ldy;          // rowdot[i*rd_stride] = (rd_bias[0] +) sum_n v(i,n) * Y(i,n)
   float* rowdot; long long rd_stride; const float* rd_bias;
   int stream_c;
+  int a_half;                             // A and Y are IEEE half in memory (lda, ldy in halves; K % 8 == 0): fp16-STORAGE scoring
   int groups;                             // set by bx3_launch
   // side job of the loader waves: side_out(i,:) = side_scale[i] * side_in(i,:), side_cols (% 4 == 0) floats per row
   const float* side_in; float* side_out; const float* side_scale; long long side_ld; int side_cols;
@@ -109,6 +110,26 @@ __device__ __forceinline__ Bx3Frag bx3_split8(const pg_v4f r0, const pg_v4f r1) 
   const bx3_u4 h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
   Bx3Frag f;
   f.h = __builtin_bit_cast(bx3_h8, h); f.m = __builtin_bit_cast(bx3_h8, m); f.l = __builtin_bit_cast(bx3_h8, l);
+  return f;
+}
+
+// Eight halves (one 16-byte read) -> fragment: a half is h + m exactly, the third plane is zero (never multiplied)
+typedef _Float16 bx3_hf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ Bx3Frag bx3_split8_half(const bx3_u4 raw) {
+  const bx3_hf8 x = __builtin_bit_cast(bx3_hf8, raw);
+  unsigned hh[4], mm[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x0 = (float)x[2 * i], x1 = (float)x[2 * i + 1];
+    bx3_f2 v = {x0, x1};
+    hh[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bx3_h2));
+    v.x = x0 - __builtin_bit_cast(float, hh[i] << 16);
+    v.y = x1 - __builtin_bit_cast(float, hh[i] & 0xffff0000u);
+    mm[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bx3_h2));
+  }
+  const bx3_u4 h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, z = {0u, 0u, 0u, 0u};
+  Bx3Frag f;
+  f.h = __builtin_bit_cast(bx3_h8, h); f.m = __builtin_bit_cast(bx3_h8, m); f.l = __builtin_bit_cast(bx3_h8, z);
   return f;
 }
 
@@ -269,7 +290,9 @@ struct Bx3Side {
   }
 };
 
-template <int NTW>
+// AH: the A operand (and the row dot's Y) are fp16 in memory.  A half is h + m exactly (8 + 3 significant bits), so the
+// fragment has two planes and a product five partial products; its rows are half the bytes (4 A blocks per k-step).
+template <int NTW, bool AH = false>
 __global__ __launch_bounds__(512, 1) void bx3_kernel(const Bx3Args p) {
   using G = Bx3Geom<NTW>;
   static_assert(G::NS == 6, "bx3_loader_loop's waits assume three steps in flight");
@@ -308,6 +331,40 @@ __global__ __launch_bounds__(512, 1) void bx3_kernel(const Bx3Args p) {
         const char* src = src0 + (size_t)s * step_bytes;
 #pragma unroll
         for (int t = 0; t < NTW; ++t) bx3_dma16s(src + t * 3072, voff, slot + (unsigned)(t * 3072));
+      }, [&](int j) { sd.step(j); }, [&]() { return sd.ops(); });
+    } else if (AH) {
+      // the panel's raw A as halves: 4 blocks = row tiles; lane fetches row 32 wr + l % 32, the 8 halves k = 16 s + 8 (l / 32)
+      const _Float16* const abase_h = reinterpret_cast<const _Float16*>(p.A) + (long long)row0 * p.lda;
+      unsigned aoffh[4], aoffh_t[4];
+      const int akoff = 8 * (lane >> 5);
+      const int klast = 16 * (ksteps - 1) + akoff;
+#pragma unroll
+      for (int wr = 0; wr < 4; ++wr) {
+        int r = 32 * wr + (lane & 31);
+        r = row0 + r < p.M ? r : p.M - 1 - row0;
+        aoffh[wr] = (unsigned)(((long long)r * p.lda + akoff) * 2);
+        const int k0 = klast <= p.K - 8 ? klast : p.K - 8;            // (K % 8 == 0: a chunk is whole or past the end)
+        aoffh_t[wr] = (unsigned)(((long long)r * p.lda + k0 - 16 * (ksteps - 1)) * 2);
+      }
+      constexpr int LPR = (32 * NTW * 2 + 127) / 128 + 1;
+      const char* const ybase = reinterpret_cast<const char*>(p.Y ? (const void*)p.Y : (const void*)p.A);
+      const long long ystride = p.Y ? p.ldy * 2 : 0;
+      const long long ymax = p.Y ? ((long long)(p.M - 1) * p.ldy + p.N) * 2 - 4 : 0;
+      bx3_loader_loop<5, G::NS>(ksteps, [&](int s) {
+        {
+          int idx = (s - 3) * 64 + lane;
+          idx = idx > 0 ? idx : 0;
+          idx = idx < G::ROWS * LPR ? idx : G::ROWS * LPR - 1;
+          long long off = (long long)(row0 + idx / LPR) * ystride + (long long)(grp * 32 * NTW) * 2 + (idx % LPR) * 128;
+          off = off < ymax ? off : ymax;
+          off &= ~3LL;
+          bx3_dma4s(ybase, (unsigned)off, lds0 + (unsigned)(G::NS * G::SLOT));
+        }
+        const unsigned slot = lds0 + (unsigned)((s % G::NS) * G::SLOT + G::A_OFF);
+        const _Float16* sb = abase_h + 16 * s;
+#pragma unroll
+        for (int wr = 0; wr < 4; ++wr)
+          bx3_dma16s(sb, s < ksteps - 1 ? aoffh[wr] : aoffh_t[wr], slot + (unsigned)(wr * 1024));
       }, [&](int j) { sd.step(j); }, [&]() { return sd.ops(); });
     } else {
       // the panel's raw A: 8 blocks = (row tile wr, k quad q): lane fetches row 32 wr + l % 32, k = 16 s + 8 (l / 32) + 4 q.
@@ -364,7 +421,14 @@ __global__ __launch_bounds__(512, 1) void bx3_kernel(const Bx3Args p) {
     sd.finish(ksteps + 1);
   } else {
     // ------------------------------- compute waves ------------------------------
-    const unsigned char* const abase = bx3_lds + G::A_OFF + wave * 2048 + lane * 16;
+    const unsigned char* const abase = bx3_lds + G::A_OFF + wave * (AH ? 1024 : 2048) + lane * 16;
+    auto read_a = [&](int slot_, pg_v4f& x0, pg_v4f& x1) {       // the raw A fragment of a slot (AH: one read, 8 halves)
+      x0 = *reinterpret_cast<const pg_v4f*>(abase + slot_ * G::SLOT);
+      if (!AH) x1 = *reinterpret_cast<const pg_v4f*>(abase + slot_ * G::SLOT + 1024);
+    };
+    auto split_a = [&](const pg_v4f& x0, const pg_v4f& x1) {
+      return AH ? bx3_split8_half(__builtin_bit_cast(bx3_u4, x0)) : bx3_split8(x0, x1);
+    };
     const unsigned char* const bbase = bx3_lds + lane * 16;
     auto read_b = [&](int slot, int t, bx3_h8& h, bx3_h8& m, bx3_h8& l) {
       const bx3_u4* q = reinterpret_cast<const bx3_u4*>(bbase + slot * G::SLOT + t * 3072);
@@ -379,7 +443,9 @@ __global__ __launch_bounds__(512, 1) void bx3_kernel(const Bx3Args p) {
     if (false)
 #endif
     {
-    Bx3Frag a = bx3_split8(*reinterpret_cast<const pg_v4f*>(abase), *reinterpret_cast<const pg_v4f*>(abase + 1024));
+    pg_v4f r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
+    read_a(0, r0, r1);
+    Bx3Frag a = split_a(r0, r1);
     bx3_h8 bh[NTW], bm[NTW], bl[NTW];
     // (read in tile order, pinned: the counted wait at the top of the loop is the stricter of the two ways in, and with
     //  tile 0 read last here it would be lgkmcnt(0) on every step -- the LDS latency of the step's last reads, exposed)
@@ -398,35 +464,28 @@ __global__ __launch_bounds__(512, 1) void bx3_kernel(const Bx3Args p) {
       // queueing on the LDS while the first MFMAs wait).  The next step's raw A fragment is requested behind tile 0 and
       // split in tile 1's region, eight VALU behind each MFMA.  (Past the last step the reads fetch a landed slot's
       // stale bytes that nothing uses.)
-      pg_v4f r0, r1;
       Bx3Frag an;
-      if (NTW == 1) {                                   // one tile: there is no "tile 1" to split behind
-        r0 = *reinterpret_cast<const pg_v4f*>(abase + nslot * G::SLOT);
-        r1 = *reinterpret_cast<const pg_v4f*>(abase + nslot * G::SLOT + 1024);
-      }
+      if (NTW == 1) read_a(nslot, r0, r1);              // one tile: there is no "tile 1" to split behind
 #pragma unroll
       for (int t = 0; t < NTW; ++t) {
         __builtin_amdgcn_sched_barrier(0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, bh[t], acc[t], 0, 0, 0);
+        if (!AH) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, bh[t], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, bl[t], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, bm[t], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, bh[t], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, bm[t], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, bh[t], acc[t], 0, 0, 0);
         if (t == (NTW > 1 ? 1 : 0)) {
-          an = bx3_split8(r0, r1);
+          an = split_a(r0, r1);
 #pragma unroll
-          for (int g = 0; g < 6; ++g) {
+          for (int g = 0; g < (AH ? 5 : 6); ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
         read_b(nslot, t, bh[t], bm[t], bl[t]);
-        if (t == 0 && NTW > 1) {
-          r0 = *reinterpret_cast<const pg_v4f*>(abase + nslot * G::SLOT);
-          r1 = *reinterpret_cast<const pg_v4f*>(abase + nslot * G::SLOT + 1024);
-        }
+        if (t == 0 && NTW > 1) read_a(nslot, r0, r1);
       }
       __builtin_amdgcn_sched_barrier(0);
       a = an;
@@ -470,7 +529,15 @@ __global__ __launch_bounds__(512, 1) void bx3_kernel(const Bx3Args p) {
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const int c = 4 * ((lane & 7) + 8 * j);
-        y[j] = (rok && col0 + c < p.N) ? *reinterpret_cast<const pg_v4f*>(p.Y + (long long)gi * p.ldy + col0 + c) : pg_v4f{0.f, 0.f, 0.f, 0.f};
+        const bool ok = rok && col0 + c < p.N;
+        if (AH) {
+          typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
+          const hf4 yh = ok ? *reinterpret_cast<const hf4*>(reinterpret_cast<const _Float16*>(p.Y) + (long long)gi * p.ldy + col0 + c)
+                            : hf4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+          y[j] = pg_v4f{(float)yh[0], (float)yh[1], (float)yh[2], (float)yh[3]};
+        } else {
+          y[j] = ok ? *reinterpret_cast<const pg_v4f*>(p.Y + (long long)gi * p.ldy + col0 + c) : pg_v4f{0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
     float part = 0.f;
@@ -503,6 +570,11 @@ __global__ __launch_bounds__(512, 1) void bx3_kernel(const Bx3Args p) {
 }
 
 inline bool bx3_eligible(const Bx3Args& p) {
+  if (p.a_half)                                        // fp16-storage scoring: A and Y halves, 16-byte chunks of 8 k
+    return p.M >= 1 && p.N >= 4 && p.N <= 320 && p.K >= 8 && (p.N & 3) == 0 && (p.K & 7) == 0 && (p.lda & 7) == 0 &&
+           aligned16(p.A) && (!p.C || ((p.ldc & 3) == 0 && aligned16(p.C))) && !p.side_in &&
+           (!p.Y || ((p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 7u) == 0 && (long long)p.M * p.ldy < (1LL << 30))) &&
+           (long long)p.M * p.lda < (1LL << 30);
   return p.M >= 1 && p.N >= 4 && p.N <= 320 && p.K >= 4 && (p.N & 3) == 0 && (p.K & 3) == 0 && (p.lda & 3) == 0 &&
          aligned16(p.A) && (!p.C || ((p.ldc & 3) == 0 && aligned16(p.C))) &&
          (!p.Y || ((p.ldy & 3) == 0 && aligned16(p.Y))) && (long long)p.M * p.lda < (1LL << 30) &&
@@ -526,21 +598,31 @@ inline void bx3_split_b(const float* B, long long b_k, long long b_n, int K, int
   hipLaunchKernelGGL(bx3_split_b_kernel, dim3(bx3_split_blocks(a)), dim3(256), 0, s, a);
 }
 
-template <int NTW>
+template <int NTW, bool AH = false>
 inline void bx3_launch_t(const Bx3Args& p, hipStream_t s) {
   using G = Bx3Geom<NTW>;
   static bool once = [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&bx3_kernel<NTW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&bx3_kernel<NTW, AH>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)G::kLdsBytes) == hipSuccess;
   }();
   (void)once;
   const unsigned panels = (unsigned)((p.M + G::ROWS - 1) / G::ROWS);
   const unsigned grid = p.groups == 2 ? ((panels + 7) / 8) * 16 : panels;
-  hipLaunchKernelGGL((bx3_kernel<NTW>), dim3(grid), dim3(G::NTHR), G::kLdsBytes, s, p);
+  hipLaunchKernelGGL((bx3_kernel<NTW, AH>), dim3(grid), dim3(G::NTHR), G::kLdsBytes, s, p);
 }
 
 inline void bx3_launch(Bx3Args p, hipStream_t s) {
   p.groups = bx3_groups(p.N);
+  if (p.a_half) {
+    switch (bx3_ntw(p.N)) {
+      case 1: bx3_launch_t<1, true>(p, s); break;
+      case 2: bx3_launch_t<2, true>(p, s); break;
+      case 3: bx3_launch_t<3, true>(p, s); break;
+      case 4: bx3_launch_t<4, true>(p, s); break;
+      default: bx3_launch_t<5, true>(p, s); break;
+    }
+    return;
+  }
   switch (bx3_ntw(p.N)) {
     case 1: bx3_launch_t<1>(p, s); break;
     case 2: bx3_launch_t<2>(p, s); break;

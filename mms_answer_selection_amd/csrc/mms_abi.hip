@@ -35,6 +35,8 @@ int simmatrix_forward(int N, int K1, int K2, const float* q, const float* a, con
                       float* top, float* qw, hipStream_t s, const float* rd_bias, void* ws = nullptr, size_t ws_bytes = 0);
 int set_matrix_mode(int mode);
 int get_matrix_mode();
+int simmatrix_forward_f16(int N, int K1, int K2, const void* q, const void* a, const float* W, float* top, void* ws,
+                          size_t ws_bytes, hipStream_t s);
 int embed_simcross_forward(int mode, int N, int W1, int W2, int D, int K, const float* index_q,
                            const float* index_a, const float* weight, const float* embed_bias, float* top,
                            float* norm0, float* norm1, hipStream_t s);
@@ -340,6 +342,14 @@ int mms_simmatrix_forward_ws_f32(int N, int K1, int K2, const float* q, const fl
   if (!q || !a || !W || !top || !qw_scratch) return MMS_ERR_INVALID_ARG;
   if (!workspace || workspace_bytes < simmatrix_workspace_bytes(N, K1, K2)) return MMS_ERR_WORKSPACE;
   return simmatrix_forward(N, K1, K2, q, a, W, top, qw_scratch, as_stream(stream), nullptr, workspace, workspace_bytes);
+}
+
+int mms_simmatrix_forward_f16(int N, int K1, int K2, const void* q_f16, const void* a_f16, const float* W, float* top,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  if (N < 0 || K1 <= 0 || K2 <= 0) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q_f16 || !a_f16 || !W || !top) return MMS_ERR_INVALID_ARG;
+  return simmatrix_forward_f16(N, K1, K2, q_f16, a_f16, W, top, workspace, workspace_bytes, as_stream(stream));
 }
 
 int mms_set_matrix_mode(int mode) { return set_matrix_mode(mode); }

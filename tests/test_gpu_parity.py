@@ -593,6 +593,42 @@ def test_simmatrix(shape, matrix_mode, oracle, hiplib):
     assert_bitexact(host(inplace), host(ga), "da scaled in place")
 
 
+@pytest.mark.parametrize("shape", [(16384, 304, 300), (2125, 64, 160), (100, 8, 4), (3000, 320, 320), (4097, 16, 36), (1, 24, 8), (2300, 1024, 64)])
+def test_simmatrix_scoring_fp16_storage(shape, oracle, hiplib):
+    """mms_simmatrix_forward_f16: q, a stored as halves, W fp32 -> fp32 scores, against the fp32 oracle run on the same
+    fp16-rounded inputs at the layer's 1e-5 (the kernel forms every fp16 x fp32 product exactly: two bf16 planes x three)."""
+    from mms_answer_selection_amd import capi
+    N, K1, K2 = shape
+    r = rng(3 * N + K1 + 5 * K2)
+    qh = (r.standard_normal((N, K1)) * 0.4).astype(np.float16)
+    ah = (r.standard_normal((N, K2)) * 0.4).astype(np.float16)
+    W = r.uniform(-0.08, 0.08, (K1, K2)).astype(np.float32)
+    top_ref, _ = oracle.simmatrix_forward(qh.astype(np.float32), ah.astype(np.float32), W)
+    top = nan_like((N, 1))
+    capi.simmatrix_forward_f16(torch.from_numpy(qh).cuda(), torch.from_numpy(ah).cuda(), dev(W), top)
+    assert_close(host(top), top_ref, TOL, "scores")
+    top2 = nan_like((N, 1))
+    capi.set_matrix_mode("fp32")                        # the fp16-storage call does not depend on the matrix mode
+    try:
+        capi.simmatrix_forward_f16(torch.from_numpy(qh).cuda(), torch.from_numpy(ah).cuda(), dev(W), top2)
+    finally:
+        capi.set_matrix_mode("bf16x3")
+    assert_bitexact(host(top2), host(top), "deterministic, mode-independent")
+
+
+def test_simmatrix_scoring_fp16_storage_refuses_what_it_cannot_do(hiplib):
+    from mms_answer_selection_amd import capi
+    q = torch.zeros((64, 12), dtype=torch.float16, device="cuda")            # K1 % 8 != 0
+    a = torch.zeros((64, 8), dtype=torch.float16, device="cuda")
+    top = torch.zeros((64, 1), device="cuda")
+    with pytest.raises(capi.MMSError):
+        capi.simmatrix_forward_f16(q, a, torch.zeros((12, 8), device="cuda"), top)
+    q = torch.zeros((64, 16), dtype=torch.float16, device="cuda")
+    a = torch.zeros((64, 324), dtype=torch.float16, device="cuda")           # K2 > 320
+    with pytest.raises(capi.MMSError):
+        capi.simmatrix_forward_f16(q, a, torch.zeros((16, 324), device="cuda"), top)
+
+
 def test_simmatrix_matrix_pipes_agree_and_mode_errors(hiplib):
     """The two pipes give the same product to fp32 rounding (both far inside 1e-5), the workspace-less entry point stays on
     the fp32 pipe, a bad mode is refused, and the documented edge of the split (inf -> NaN) is what happens."""

@@ -1,0 +1,34 @@
+"""tools/sm16_probe.py -- dev probe: fp16-storage SimMatrix scoring (mms_simmatrix_forward_f16) next to the fp32 forward,
+16384 x 300(304) x 300, hipGraph-replayed."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mms_answer_selection_amd import capi
+
+def gtime(fn, iters=16, reps=5):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(2): fn()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(iters): fn()
+        g.replay(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s); g.replay(); e1.record(s); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1000 / iters)
+    return sorted(ts)[len(ts) // 2]
+
+N, K1, K2 = 16384, 304, 300
+g = torch.Generator(device="cuda").manual_seed(3)
+q = torch.randn(N, K1, device="cuda", generator=g) * 0.4
+a = torch.randn(N, K2, device="cuda", generator=g) * 0.4
+W = torch.rand(K1, K2, device="cuda", generator=g) * 0.16 - 0.08
+qh, ah = q.half(), a.half()
+top, scr = torch.empty(N, 1, device="cuda"), torch.empty(N, K2, device="cuda")
+ws = capi.Workspace()
+print("fp32 storage, forward (scores + Q.W):  %.2f us" % gtime(lambda: capi.simmatrix_forward(q, a, W, top, scr, ws=ws)))
+print("fp16 storage, scoring (scores only):   %.2f us" % gtime(lambda: capi.simmatrix_forward_f16(qh, ah, W, top, ws=ws)))
+ref = ((qh.double() @ W.double()) * ah.double()).sum(1, keepdim=True)
+print("max |err| vs fp64 on the rounded inputs: %.3e (max |ref| %.2f)" % ((top.double() - ref).abs().max().item(), ref.abs().max().item()))
