@@ -1091,6 +1091,18 @@ def other_configs(torch, capi):
         "executed_TFLOPs": done / us / 1e6, "executed_frac_mfma_fp32_peak": done / (us * 1e-6) / 157.3e12,
         "bound": "mfma", "dtype": "f32", "matrix_mode": "fp32"}
 
+    # fp16-STORAGE scoring with the learned metric (round 3): q, a as halves (K1 padded to 304 = a multiple of 8), W fp32,
+    # scores only -- the bilinear member of the fp16-storage family (mms_simmatrix_forward_f16)
+    q16 = torch.zeros(N, 304, device="cuda", dtype=torch.float16); q16[:, :K] = q.half()
+    a16 = a.half()
+    W16 = torch.zeros(304, K, device="cuda"); W16[:K] = W
+    us = _graph_time(torch, lambda: capi.simmatrix_forward_f16(q16, a16, W16, top, ws=ws), iters=16)
+    out["simmatrix_scoring_16384x304x300_fp16_storage"] = {
+        "us_per_step": us, "pairs_per_s": N / (us * 1e-6), "TFLOPs": (2.0 * N * K * K + 2.0 * N * K) / us / 1e6,
+        "dtype": "f16 storage / exact bf16 x 2 x 3 products, f32 accumulate", "bound": "mfma (bf16 pipe) / L2->LDS operand stream",
+        "note": "mms_simmatrix_forward_f16: scores only (no Q.W output); the fp32-storage forward above writes Q.W too"}
+    del q16, a16, W16
+
     def cfg3_nocache():
         capi.simmatrix_forward(q, a, W, top, scr, ws=ws)
         capi.simmatrix_backward(q, a, W, dT, dq, da, dW, ws=ws)
