@@ -189,7 +189,7 @@ __device__ __forceinline__ void bx3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0
 // the loader's loop: PER DMAs per k-step, issued by issue(step)
 template <int PER, int NS, class Issue, class Side, class SideOps>
 __device__ __forceinline__ void bx3_loader_loop(int ksteps, Issue&& issue, Side&& side, SideOps&& side_ops) {
-#if defined(MMS_BX3_ABLATE) && MMS_BX3_ABLATE == 4
+#if defined(MMS_BX3_ABLATE) && MMS_BX3_ABLATE == 4       // MMS_BX3_ABLATE / MMS_BX3TN_ABLATE: dev-only timing ablations (tools/bx3bench.hip)
   __builtin_amdgcn_s_barrier();
   return;
 #endif

@@ -41,9 +41,14 @@ for it in range(runs):
     upd("dq", dq, dT.double() * (a.double() @ W.double().T))
     upd("da (cached)", da, dT.double() * P)
     upd("dW", dW, q.double().T @ (dT.double() * a.double()))
+    if K1 % 8 == 0:                                             # the fp16-storage scoring entry point on the rounded inputs
+        qh, ah = q.half(), a.half()
+        t16 = torch.empty(N, 1, device="cuda")
+        capi.simmatrix_forward_f16(qh, ah, W, t16, ws=ws)
+        upd("top (fp16 storage)", t16, ((qh.double() @ W.double()) * ah.double()).sum(1, keepdim=True))
     da2, dq2, dW2 = torch.empty_like(a), torch.empty_like(q), torch.zeros_like(W)
     capi.simmatrix_backward(q, a, W, dT, dq2, da2, dW2, ws=ws)
     assert torch.equal(da2, da) and torch.equal(dq2, dq) and torch.equal(dW2, dW), "cached and recomputing backward differ"
 print("soak_bx3: %d random shapes x 4 value distributions, worst |err| / max(1, max|ref|):" % runs)
 for k, v in worst.items():
-    print("   %-12s %.3e %s" % (k, v, "OK" if v <= 1e-5 else "** over 1e-5 **"))
+    print("   %-20s %.3e %s" % (k, v, "OK" if v <= 1e-5 else "** over 1e-5 **"))
