@@ -3,6 +3,8 @@
 // 30 v_mfma_f32_32x32x16_bf16 (5 accumulator tiles x 6) on random-ish operands:
 //   MODE 0: MFMAs only (operands in registers)            1: + one s_barrier per step (8 waves)
 //   MODE 2: + 17 ds_read_b128 per step (next step's frags) 3: 1 + 2                4: 3 + 60 VALU per step
+//   MODE 5: 3 + the PARTNER wave of each SIMD issues 180 dependent-free VALU per step between the barriers
+//   MODE 6: 3 + 180 VALU per step in the compute wave's OWN stream (6 behind each MFMA)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/bx3struct.hip -o /tmp/bx3struct && /tmp/bx3struct
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -20,9 +22,20 @@ __global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* stam
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int i = threadIdx.x; i < 32768; i += 512) reinterpret_cast<unsigned*>(lds)[i] = (seed * 2654435761u + i * 40503u) & 0x3fff3fffu | 0x3c003c00u;
   __syncthreads();
-  constexpr bool BAR = MODE == 1 || MODE == 3 || MODE == 4, RD = MODE >= 2, VAL = MODE == 4;
+  constexpr bool BAR = MODE == 1 || MODE >= 3, RD = MODE >= 2, VAL = MODE == 4, OWN = MODE == 6;
   if (wave >= 4) {
-    if (BAR) for (int s = 0; s < steps; ++s) __builtin_amdgcn_s_barrier();
+    float pv[12];
+    for (int i = 0; i < 12; ++i) pv[i] = lane * 0.01f + i;
+    if (BAR) for (int s = 0; s < steps; ++s) {
+      if (MODE == 5) {
+#pragma unroll
+        for (int r = 0; r < 15; ++r)
+#pragma unroll
+          for (int i = 0; i < 12; ++i) pv[i] = pv[i] * 1.0001f + 0.5f;
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    if (MODE == 5) { float z = 0; for (int i = 0; i < 12; ++i) z += pv[i]; out[blockIdx.x * 256 + (threadIdx.x & 255)] = z; }
     return;
   }
   f16v acc[5];
@@ -49,6 +62,12 @@ __global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* stam
         for (int i = 0; i < 12; ++i) v[i & 7] = v[i & 7] * 1.0001f + 0.5f;
 #pragma unroll
         for (int g = 0; g < 6; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+      }
+      if (OWN) {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) v[i & 7] = v[i & 7] * 1.0001f + 0.5f;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (RD) {
@@ -90,6 +109,8 @@ int main() {
   run<2>("+ 15 ds_read_b128 per step (no barrier)", out, st, steps);
   run<3>("+ barrier + reads", out, st, steps);
   run<4>("+ barrier + reads + 60 VALU", out, st, steps);
+  run<5>("+ barrier + reads + 180 VALU per step in the PARTNER wave", out, st, steps);
+  run<6>("+ barrier + reads + 180 VALU per step in the SAME wave", out, st, steps);
   run<0>("MFMAs only (again)", out, st, steps);
   return 0;
 }
