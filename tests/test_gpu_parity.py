@@ -235,7 +235,7 @@ def test_euclid_subnormal_squares(oracle, hiplib):
     assert_bitexact(host(ga), da_ref, "da")
 
 
-@pytest.mark.parametrize("cfg", [(8192, 1024), (33, 1024), (5, 8), (17, 2048), (9, 304)])
+@pytest.mark.parametrize("cfg", [(8192, 1024), (33, 1024), (5, 8), (17, 2048), (9, 304), (21, 520), (5, 408), (1, 1024), (4099, 512)])
 def test_euclid_fp16_storage(cfg, oracle, hiplib):
     """BASELINE cfg 5: half in HBM, fp32 reference arithmetic.  Against the fp32 oracle run on
     the widened inputs: scores bit-exact, gradients equal to the oracle's rounded to half."""
