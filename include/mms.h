@@ -41,7 +41,7 @@ extern "C" {
 /* 0.2.0: mms_embed_simcross_forward_f32 gained `embed_bias`, mms_rank_workspace_bytes and the mms_layer_t option
  * table changed (round 2), the triplet workspace carries the arrival words and must be initialised (round 3).
  * A host built against another header must refuse to run: compare mms_version() with MMS_VERSION at start-up. */
-#define MMS_VERSION 211
+#define MMS_VERSION 212
 
 enum {
   MMS_OK = 0,
@@ -264,6 +264,18 @@ int mms_get_matrix_mode(void);
 int mms_simmatrix_forward_f16(int N, int K1, int K2, const void* q_f16, const void* a_f16,
                               const float* W, float* top, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* The TRAINING pair of the same family: the forward also leaves Q*W (fp32, (N,K2)) in qw_scratch; the backward
+ * (sim_matrix_layer.cpp:68-95) takes it back and writes dq (N,K1) and da (N,K2) as halves (rounded RNE from the fp32
+ * values; either may be NULL = not propagated) and ACCUMULATES dW (K1,K2) in fp32 (NULL = not propagated).  K1 % 8 == 0
+ * and K2 % 8 == 0 (both products take a half operand along their inner dimension), K1, K2 <= 320.  Against the fp32
+ * layer on the widened inputs: scores and dW at 1e-5, dq / da at half precision (1e-3). */
+int mms_simmatrix_forward_train_f16(int N, int K1, int K2, const void* q_f16, const void* a_f16,
+                                    const float* W, float* top, float* qw_scratch, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+int mms_simmatrix_backward_f16(int N, int K1, int K2, const void* q_f16, const void* a_f16,
+                               const float* W, const float* qw, const float* top_diff,
+                               void* dq_f16, void* da_f16, float* dW, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* Replaces SimMatrixLayer<float>::Backward_cpu / Backward_gpu
  *   src/caffe/layers/sim_matrix_layer.cpp:68-95, sim_matrix_layer.cu:43-46.

@@ -31,6 +31,8 @@ _SIGNATURES = {
     "mms_simmatrix_forward_f32": (_i, [_i] * 3 + [_vp] * 6),
     "mms_simmatrix_forward_ws_f32": (_i, [_i] * 3 + [_vp] * 6 + [_sz, _vp]),
     "mms_simmatrix_forward_f16": (_i, [_i] * 3 + [_vp] * 5 + [_sz, _vp]),
+    "mms_simmatrix_forward_train_f16": (_i, [_i] * 3 + [_vp] * 6 + [_sz, _vp]),
+    "mms_simmatrix_backward_f16": (_i, [_i] * 3 + [_vp] * 9 + [_sz, _vp]),
     "mms_set_matrix_mode": (_i, [_i]),
     "mms_get_matrix_mode": (_i, []),
     "mms_simmatrix_backward_f32": (_i, [_i] * 3 + [_vp] * 4 + [_i] * 3 + [_vp] * 4 + [_sz, _vp]),
@@ -94,7 +96,7 @@ class MMSError(RuntimeError):
     pass
 
 
-MMS_VERSION = 211      # include/mms.h
+MMS_VERSION = 212      # include/mms.h
 
 
 def lib():
@@ -256,6 +258,28 @@ def simmatrix_forward_f16(q, a, W, top, ws=None):
     wsp, wsb = (ws or _default_ws).get(lib().mms_simmatrix_workspace_bytes(N, K1, K2), q.device)
     check(lib().mms_simmatrix_forward_f16(N, K1, K2, _ptr(q, "q", dtype=h), _ptr(a, "a", dtype=h), _ptr(W, "W"),
                                           _ptr(top, "top"), wsp, wsb, _stream()), "mms_simmatrix_forward_f16")
+
+
+def simmatrix_forward_train_f16(q, a, W, top, qw_scratch, ws=None):
+    N = q.shape[0]
+    K1, K2 = W.shape
+    h = torch.float16
+    wsp, wsb = (ws or _default_ws).get(lib().mms_simmatrix_workspace_bytes(N, K1, K2), q.device)
+    check(lib().mms_simmatrix_forward_train_f16(N, K1, K2, _ptr(q, "q", dtype=h), _ptr(a, "a", dtype=h), _ptr(W, "W"),
+                                                _ptr(top, "top"), _ptr(qw_scratch, "qw_scratch"), wsp, wsb, _stream()),
+          "mms_simmatrix_forward_train_f16")
+
+
+def simmatrix_backward_f16(q, a, W, qw, top_diff, dq, da, dW, ws=None):
+    """dq, da: half tensors or None; dW: float32 (accumulated into) or None."""
+    N = q.shape[0]
+    K1, K2 = W.shape
+    h = torch.float16
+    wsp, wsb = (ws or _default_ws).get(lib().mms_simmatrix_workspace_bytes(N, K1, K2), q.device)
+    check(lib().mms_simmatrix_backward_f16(N, K1, K2, _ptr(q, "q", dtype=h), _ptr(a, "a", dtype=h), _ptr(W, "W"),
+                                           _ptr(qw, "qw", True), _ptr(top_diff, "top_diff"), _ptr(dq, "dq", True, h),
+                                           _ptr(da, "da", True, h), _ptr(dW, "dW", True), wsp, wsb, _stream()),
+          "mms_simmatrix_backward_f16")
 
 
 def set_matrix_mode(mode):

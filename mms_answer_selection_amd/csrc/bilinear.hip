@@ -1640,6 +1640,82 @@ int simmatrix_forward_f16(int N, int K1, int K2, const void* q, const void* a, c
   return launch_status();
 }
 
+// da (halves) = diag(dT) . P  (P fp32: the training forward's Q.W), RNE at the store
+__global__ __launch_bounds__(256) void rowscale_to_half_kernel(const float4* __restrict__ P, const float* __restrict__ dT,
+                                                               void* __restrict__ out, long long rows, int cols4) {
+  typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
+  const long long n = rows * cols4, stride = (long long)gridDim.x * 256;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
+    const float4 v = P[e];
+    const float sc = dT[e / cols4];
+    const hf4 o = {(_Float16)(0.f + sc * v.x), (_Float16)(0.f + sc * v.y), (_Float16)(0.f + sc * v.z), (_Float16)(0.f + sc * v.w)};
+    __builtin_nontemporal_store(o, reinterpret_cast<hf4*>(out) + e);
+  }
+}
+
+// fp16-STORAGE training forward / backward of SimMatrix (round 3): q, a and the bottom gradients dq, da are halves in
+// HBM; W, dW, the scores, top_diff and the forward's Q.W (qw, (N, K2), the scratch the backward scales into da) fp32.
+// All three products run on the bf16 pipe with the half operands split exactly into two planes (bx3_gemm.h);
+// gradients are rounded to half (RNE) at the store.  No fp32 fallback: MMS_ERR_UNSUPPORTED outside the kernels' shapes.
+int simmatrix_forward_train_f16(int N, int K1, int K2, const void* q, const void* a, const float* W, float* top, float* qw,
+                                void* ws, size_t ws_bytes, hipStream_t s) {
+  const SimMatrixWs lay = simmatrix_ws(N, K1, K2);
+  if (!ws || ws_bytes < lay.total) return MMS_ERR_WORKSPACE;
+  Bx3Args b{};
+  b.M = N; b.N = K2; b.K = K1; b.A = static_cast<const float*>(q); b.lda = K1; b.a_half = 1; b.C = qw; b.ldc = K2;
+  b.Y = static_cast<const float*>(a); b.ldy = K2; b.rowdot = top; b.rd_stride = 1;
+  if (!bx3_eligible(b)) return MMS_ERR_UNSUPPORTED;
+  bx3_u4* img = reinterpret_cast<bx3_u4*>(static_cast<char*>(ws) + lay.img_off);
+  b.img = img;
+  bx3_split_b(W, K2, 1, K1, K2, img, s, bx3_groups(K2) == 2 ? top : nullptr, 1, N);
+  bx3_launch(b, s);
+  return launch_status();
+}
+int simmatrix_backward_f16(int N, int K1, int K2, const void* q, const void* a, const float* W, const float* qw,
+                           const float* top_diff, void* dq, void* da, float* dW, void* ws, size_t ws_bytes, hipStream_t s) {
+  const SimMatrixWs lay = simmatrix_ws(N, K1, K2);
+  if (!ws || ws_bytes < lay.total) return MMS_ERR_WORKSPACE;
+  char* base = static_cast<char*>(ws);
+  float* part = reinterpret_cast<float*>(base + lay.part_off);
+  bx3_u4* img = reinterpret_cast<bx3_u4*>(base + lay.img_off);
+  Bx3TnArgs t{};
+  t.M = K1; t.N = K2; t.K = N; t.A = static_cast<const float*>(q); t.lda = K1; t.B = static_cast<const float*>(a); t.ldb = K2;
+  t.kscale = top_diff; t.C = part; t.c_ks = (long long)K1 * K2; t.ab_half = 1;
+  t.nchunks = bx3_tn_pick_chunks(N, bx3_tn_quads(K1, K2), &t.kchunk);
+  Bx3Args bq{};
+  bq.M = N; bq.N = K1; bq.K = K2; bq.A = static_cast<const float*>(a); bq.lda = K2; bq.a_half = 1;
+  bq.C = static_cast<float*>(dq); bq.ldc = K1; bq.c_half = 1; bq.rowscale = top_diff; bq.stream_c = 1; bq.img = img;
+  bool da_side = false;
+  if (dq && da && qw && K2 >= 8) {                 // da rides in the dq launch's loader waves (as in the fp32 path)
+    bq.side_in = qw; bq.side_out = static_cast<float*>(da); bq.side_scale = top_diff; bq.side_ld = K2; bq.side_cols = K2;
+    bq.side_half = 1;
+    da_side = bx3_eligible(bq);
+    if (!da_side) { bq.side_in = nullptr; bq.side_out = nullptr; bq.side_scale = nullptr; bq.side_half = 0; }
+  }
+  if ((dW && !bx3_tn_eligible(t)) || (dq && !bx3_eligible(bq)) || (da && (!qw || (K2 & 3) != 0 || !aligned16(qw) ||
+                                                                         (reinterpret_cast<uintptr_t>(da) & 7u) != 0)))
+    return MMS_ERR_UNSUPPORTED;
+  if (dW) {
+    // dW += Q^T diag(dT) A   (:73-80), both operands widened and split on the fly
+    bx3_tn_launch(t, s);
+    const unsigned rb = ew_blocks((long long)K1 * K2);
+    if (dq) {
+      const Bx3SplitArgs sp = bx3_split_args(W, 1, K2, K2, K1, img);
+      hipLaunchKernelGGL(splitk_reduce_split_kernel, dim3(rb + bx3_split_blocks(sp)), dim3(256), 0, s, part, t.nchunks,
+                         (long long)K1 * K2, dW, 1, (int)rb, sp);
+    } else {
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, part, t.nchunks, (long long)K1 * K2, dW, 1);
+    }
+  } else if (dq) {
+    bx3_split_b(W, 1, K2, K2, K1, img, s);
+  }
+  if (dq) bx3_launch(bq, s);                       // dq_j = dT_j * (W a_j)   (:88, NoTrans)
+  if (da && !da_side)                              // da_j = dT_j * (W^T q_j) (:88, Trans): the forward's product, scaled
+    hipLaunchKernelGGL(rowscale_to_half_kernel, dim3(ew_blocks((long long)N * (K2 / 4))), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(qw), top_diff, da, (long long)N, K2 / 4);
+  return launch_status();
+}
+
 // qw (optional): the forward's Q.W, unchanged since; may alias da.  da_j = dT_j * (W^T q_j) is row j of
 // Q.W scaled by dT_j -- the product the forward already made with the same kernel and k order, so
 // reusing it returns the same bits as recomputing it and saves one of the four GEMMs of a step.

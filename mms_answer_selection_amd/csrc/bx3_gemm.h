@@ -62,9 +62,11 @@ struct Bx3Args {
   float* rowdot; long long rd_stride; const float* rd_bias;
   int stream_c;
   int a_half;                             // A and Y are IEEE half in memory (lda, ldy in halves; K % 8 == 0): fp16-STORAGE scoring
+  int c_half;                             // C is IEEE half in memory (ldc in halves; values rounded RNE at the store)
   int groups;                             // set by bx3_launch
   // side job of the loader waves: side_out(i,:) = side_scale[i] * side_in(i,:), side_cols (% 4 == 0) floats per row
   const float* side_in; float* side_out; const float* side_scale; long long side_ld; int side_cols;
+  int side_half;                          // side_out is IEEE half in memory (side_ld = its row stride in halves too; side_in stays fp32)
 };
 
 template <int NTW>
@@ -230,6 +232,7 @@ struct Bx3Side {
   static constexpr int SLOT = 4096 + 1024;          // 256 lanes x (16 + 4) bytes per step
   static constexpr int BYTES = 4 * SLOT;
   const float* in; float* out; const float* scale; long long ld;
+  int out_half;
   int row0, total, c0, nc;         // rows from row0, total = rows * nc float4, float4 columns [c0, c0 + nc)
   int lane, w;                     // loader wave w
   int cnt;                         // float4 per lane: indices 0 .. cnt-1 (index i is requested at step i)
@@ -239,7 +242,7 @@ struct Bx3Side {
 
   __device__ __forceinline__ void init(const Bx3Args& p, int r0, int grp, int ngroups, int rows_per_wg, int w_, int lane_,
                                        unsigned lds_byte, const unsigned char* lds_ptr) {
-    in = p.side_in; out = p.side_out; scale = p.side_scale; ld = p.side_ld;
+    in = p.side_in; out = p.side_out; scale = p.side_scale; ld = p.side_ld; out_half = p.side_half;
     const int SC = p.side_cols >> 2, half = (SC + 1) >> 1;
     c0 = ngroups == 2 ? grp * half : 0;
     nc = ngroups == 2 ? (grp ? SC - half : half) : SC;
@@ -266,7 +269,14 @@ struct Bx3Side {
     const float sc = *reinterpret_cast<const float*>(slot + 4096 + w * 256 + lane * 4);
     if (f < total) {
       const int r = f / nc, cc = f - r * nc;
-      __builtin_nontemporal_store(sc * x, reinterpret_cast<pg_v4f*>(out + (long long)(row0 + r) * ld + 4 * (c0 + cc)));
+      const pg_v4f v = sc * x;
+      if (out_half) {
+        typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
+        const hf4 o = {(_Float16)(0.f + v[0]), (_Float16)(0.f + v[1]), (_Float16)(0.f + v[2]), (_Float16)(0.f + v[3])};
+        __builtin_nontemporal_store(o, reinterpret_cast<hf4*>(reinterpret_cast<_Float16*>(out) + (long long)(row0 + r) * ld + 4 * (c0 + cc)));
+      } else {
+        __builtin_nontemporal_store(v, reinterpret_cast<pg_v4f*>(out + (long long)(row0 + r) * ld + 4 * (c0 + cc)));
+      }
     }
   }
   __device__ __forceinline__ int ops() const { return n1 + n2 + n3; }     // among the youngest at the next wait
@@ -549,9 +559,17 @@ __global__ __launch_bounds__(512, 1) void bx3_kernel(const Bx3Args p) {
         if (p.rowscale) v *= sc;
         if (p.Y) { part += v[0] * y[j][0]; part += v[1] * y[j][1]; part += v[2] * y[j][2]; part += v[3] * y[j][3]; }
         if (p.C) {
-          pg_v4f* dst = reinterpret_cast<pg_v4f*>(p.C + (long long)gi * p.ldc + col0 + c);
-          if (p.stream_c) __builtin_nontemporal_store(v, dst);
-          else *dst = v;
+          if (AH && p.c_half) {                            // (fp16-storage family only: the flag is not read otherwise)
+            typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
+            const hf4 o = {(_Float16)(0.f + v[0]), (_Float16)(0.f + v[1]), (_Float16)(0.f + v[2]), (_Float16)(0.f + v[3])};
+            hf4* dst = reinterpret_cast<hf4*>(reinterpret_cast<_Float16*>(p.C) + (long long)gi * p.ldc + col0 + c);
+            if (p.stream_c) __builtin_nontemporal_store(o, dst);
+            else *dst = o;
+          } else {
+            pg_v4f* dst = reinterpret_cast<pg_v4f*>(p.C + (long long)gi * p.ldc + col0 + c);
+            if (p.stream_c) __builtin_nontemporal_store(v, dst);
+            else *dst = v;
+          }
         }
       }
     }
@@ -572,7 +590,10 @@ __global__ __launch_bounds__(512, 1) void bx3_kernel(const Bx3Args p) {
 inline bool bx3_eligible(const Bx3Args& p) {
   if (p.a_half)                                        // fp16-storage scoring: A and Y halves, 16-byte chunks of 8 k
     return p.M >= 1 && p.N >= 4 && p.N <= 320 && p.K >= 8 && (p.N & 3) == 0 && (p.K & 7) == 0 && (p.lda & 7) == 0 &&
-           aligned16(p.A) && (!p.C || ((p.ldc & 3) == 0 && aligned16(p.C))) && !p.side_in &&
+           aligned16(p.A) && (!p.C || ((p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & (p.c_half ? 7u : 15u)) == 0)) &&
+           (!p.side_in || ((p.side_cols & 3) == 0 && p.side_cols >= 8 && (p.side_ld & 3) == 0 && aligned16(p.side_in) && p.side_scale &&
+                           (reinterpret_cast<uintptr_t>(p.side_out) & (p.side_half ? 7u : 15u)) == 0 &&
+                           (long long)p.M * p.side_ld < (1LL << 30))) &&
            (!p.Y || ((p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 7u) == 0 && (long long)p.M * p.ldy < (1LL << 30))) &&
            (long long)p.M * p.lda < (1LL << 30);
   return p.M >= 1 && p.N >= 4 && p.N <= 320 && p.K >= 4 && (p.N & 3) == 0 && (p.K & 3) == 0 && (p.lda & 3) == 0 &&
@@ -651,6 +672,7 @@ struct Bx3TnArgs {
   const float* A; long long lda;
   const float* B; long long ldb;
   const float* kscale;                   // K values, or null
+  int ab_half;                           // A and B are IEEE half in memory (lda, ldb in halves): the fp16-storage family
   float* C; long long c_ks;              // slab ks at C + ks * c_ks, row stride N
   int kchunk, nchunks;                   // pairs per chunk (a multiple of 32), chunks
 };
@@ -728,6 +750,12 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
           const float* pu = xb[u] + (long long)(nb + 8 * g) * ld[u] + colc[u];
+          if (p.ab_half) {
+            const _Float16* ph = reinterpret_cast<const _Float16*>(xb[u]) + (long long)(nb + 8 * g) * ld[u] + colc[u];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { raw[R][u][j] = (float)*ph; ph += ld[u]; }
+            continue;
+          }
 #pragma unroll
           for (int j = 0; j < 8; ++j) { raw[R][u][j] = *pu; pu += ld[u]; }
         }
@@ -742,7 +770,9 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
         const float kv = ksp ? ksp[n] : 1.f;                    // (wave-uniform choice: no divergent branch)
         ksc[R][j] = ok ? kv : 0.f;                              // pairs past the chunk's end add zero
 #pragma unroll
-        for (int u = 0; u < 5; ++u) raw[R][u][j] = xb[u][(long long)n * ld[u] + colc[u]];
+        for (int u = 0; u < 5; ++u)
+          raw[R][u][j] = p.ab_half ? (float)reinterpret_cast<const _Float16*>(xb[u])[(long long)n * ld[u] + colc[u]]
+                                   : xb[u][(long long)n * ld[u] + colc[u]];
       }
     };
     auto emit = [&](auto stage, int buf) {

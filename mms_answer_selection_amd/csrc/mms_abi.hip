@@ -37,6 +37,10 @@ int set_matrix_mode(int mode);
 int get_matrix_mode();
 int simmatrix_forward_f16(int N, int K1, int K2, const void* q, const void* a, const float* W, float* top, void* ws,
                           size_t ws_bytes, hipStream_t s);
+int simmatrix_forward_train_f16(int N, int K1, int K2, const void* q, const void* a, const float* W, float* top, float* qw,
+                                void* ws, size_t ws_bytes, hipStream_t s);
+int simmatrix_backward_f16(int N, int K1, int K2, const void* q, const void* a, const float* W, const float* qw,
+                           const float* top_diff, void* dq, void* da, float* dW, void* ws, size_t ws_bytes, hipStream_t s);
 int embed_simcross_forward(int mode, int N, int W1, int W2, int D, int K, const float* index_q,
                            const float* index_a, const float* weight, const float* embed_bias, float* top,
                            float* norm0, float* norm1, hipStream_t s);
@@ -350,6 +354,24 @@ int mms_simmatrix_forward_f16(int N, int K1, int K2, const void* q_f16, const vo
   if (N == 0) return MMS_OK;
   if (!q_f16 || !a_f16 || !W || !top) return MMS_ERR_INVALID_ARG;
   return simmatrix_forward_f16(N, K1, K2, q_f16, a_f16, W, top, workspace, workspace_bytes, as_stream(stream));
+}
+
+int mms_simmatrix_forward_train_f16(int N, int K1, int K2, const void* q_f16, const void* a_f16, const float* W, float* top,
+                                    float* qw_scratch, void* workspace, size_t workspace_bytes, void* stream) {
+  if (N < 0 || K1 <= 0 || K2 <= 0) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q_f16 || !a_f16 || !W || !top || !qw_scratch) return MMS_ERR_INVALID_ARG;
+  return simmatrix_forward_train_f16(N, K1, K2, q_f16, a_f16, W, top, qw_scratch, workspace, workspace_bytes, as_stream(stream));
+}
+
+int mms_simmatrix_backward_f16(int N, int K1, int K2, const void* q_f16, const void* a_f16, const float* W, const float* qw,
+                               const float* top_diff, void* dq_f16, void* da_f16, float* dW, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (N < 0 || K1 <= 0 || K2 <= 0) return MMS_ERR_INVALID_ARG;
+  if (N == 0) return MMS_OK;
+  if (!q_f16 || !a_f16 || !W || !top_diff) return MMS_ERR_INVALID_ARG;
+  return simmatrix_backward_f16(N, K1, K2, q_f16, a_f16, W, qw, top_diff, dq_f16, da_f16, dW, workspace, workspace_bytes,
+                                as_stream(stream));
 }
 
 int mms_set_matrix_mode(int mode) { return set_matrix_mode(mode); }

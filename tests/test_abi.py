@@ -25,7 +25,7 @@ def test_header_symbols_exported(hiplib):
 
 
 def test_version_and_error_strings(hiplib):
-    assert hiplib.mms_version() == 211          # include/mms.h MMS_VERSION: bumped with every incompatible change
+    assert hiplib.mms_version() == 212          # include/mms.h MMS_VERSION: bumped with every incompatible change
     assert hiplib.mms_error_string(0) == b"ok"
     assert b"workspace" in hiplib.mms_error_string(3)
 

@@ -616,6 +616,43 @@ def test_simmatrix_scoring_fp16_storage(shape, oracle, hiplib):
     assert_bitexact(host(top2), host(top), "deterministic, mode-independent")
 
 
+@pytest.mark.parametrize("shape", [(16384, 304, 304), (2125, 64, 160), (100, 8, 8), (3000, 320, 320), (4097, 16, 40), (1, 24, 8)])
+def test_simmatrix_training_fp16_storage(shape, oracle, hiplib):
+    """mms_simmatrix_forward_train_f16 / mms_simmatrix_backward_f16: q, a, dq, da stored as halves; W, dW, scores, top_diff
+    and the Q.W scratch fp32.  Against the fp32 oracle on the fp16-rounded inputs: scores, Q.W and dW at 1e-5 (products of
+    widened halves are formed exactly), dq / da at half precision."""
+    from mms_answer_selection_amd import capi
+    N, K1, K2 = shape
+    r = rng(5 * N + K1 + 3 * K2)
+    qh = (r.standard_normal((N, K1)) * 0.4).astype(np.float16)
+    ah = (r.standard_normal((N, K2)) * 0.4).astype(np.float16)
+    W = r.uniform(-0.08, 0.08, (K1, K2)).astype(np.float32)
+    dT = r.standard_normal((N, 1)).astype(np.float32)
+    dW0 = r.standard_normal((K1, K2)).astype(np.float32)
+    q32, a32 = qh.astype(np.float32), ah.astype(np.float32)
+    top_ref, qw_ref = oracle.simmatrix_forward(q32, a32, W)
+    dq_ref, da_ref, dW_ref = oracle.simmatrix_backward(q32, a32, W, dT, dW_in=dW0)
+    qd, ad, Wd, dTd = torch.from_numpy(qh).cuda(), torch.from_numpy(ah).cuda(), dev(W), dev(dT)
+    top, qw = nan_like((N, 1)), nan_like((N, K2))
+    capi.simmatrix_forward_train_f16(qd, ad, Wd, top, qw)
+    assert_close(host(top), top_ref, TOL, "scores")
+    assert_close(host(qw), qw_ref, TOL, "Q*W scratch")
+    mk = lambda shp: torch.full(shp, float("nan"), dtype=torch.float16, device="cuda")
+    gq, ga, gW = mk((N, K1)), mk((N, K2)), dev(dW0)
+    capi.simmatrix_backward_f16(qd, ad, Wd, qw, dTd, gq, ga, gW)
+    assert_close(host(gW), dW_ref, 2e-5 if N > 8192 else TOL, "dW (accumulated)")
+    for got, ref, what in ((gq, dq_ref, "dq"), (ga, da_ref, "da")):
+        g = host(got).astype(np.float32)
+        assert np.isfinite(g).all(), what
+        assert (np.abs(g - ref) <= np.abs(ref) * 2.0 ** -10 + 1e-5 * max(1.0, np.abs(ref).max()) + 2.0 ** -24).all(), what
+    # propagate flags: NULL outputs are left alone, dW only when asked
+    gq2, gW2 = mk((N, K1)), dev(dW0)
+    capi.simmatrix_backward_f16(qd, ad, Wd, qw, dTd, gq2, None, None)
+    assert (host(gq2).view(np.uint16) == host(gq).view(np.uint16)).all(), "dq alone"
+    capi.simmatrix_backward_f16(qd, ad, Wd, None, dTd, None, None, gW2)
+    assert_bitexact(host(gW2), host(gW), "dW alone")
+
+
 def test_simmatrix_scoring_fp16_storage_refuses_what_it_cannot_do(hiplib):
     from mms_answer_selection_amd import capi
     q = torch.zeros((64, 12), dtype=torch.float16, device="cuda")            # K1 % 8 != 0
