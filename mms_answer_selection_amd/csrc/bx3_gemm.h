@@ -693,6 +693,9 @@ inline int bx3_tn_pick_chunks(int K, int quads, int* kchunk) {
 }
 inline int bx3_tn_quads(int M, int N) { return ((M + BX3TN_Q - 1) / BX3TN_Q) * ((N + BX3TN_Q - 1) / BX3TN_Q); }
 
+// HALF: A and B are IEEE half in memory (a template parameter: as a run-time flag the second load form cost the fp32 kernel
+// 72 VGPRs and 1 KB of scratch -- cfg 3's dW 34 -> 48 us)
+template <bool HALF>
 __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tn_lds[];
   const int lane = threadIdx.x & 63;
@@ -750,7 +753,7 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
           const float* pu = xb[u] + (long long)(nb + 8 * g) * ld[u] + colc[u];
-          if (p.ab_half) {
+          if (HALF) {
             const _Float16* ph = reinterpret_cast<const _Float16*>(xb[u]) + (long long)(nb + 8 * g) * ld[u] + colc[u];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { raw[R][u][j] = (float)*ph; ph += ld[u]; }
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
         ksc[R][j] = ok ? kv : 0.f;                              // pairs past the chunk's end add zero
 #pragma unroll
         for (int u = 0; u < 5; ++u)
-          raw[R][u][j] = p.ab_half ? (float)reinterpret_cast<const _Float16*>(xb[u])[(long long)n * ld[u] + colc[u]]
+          raw[R][u][j] = HALF ? (float)reinterpret_cast<const _Float16*>(xb[u])[(long long)n * ld[u] + colc[u]]
                                    : xb[u][(long long)n * ld[u] + colc[u]];
       }
     };
@@ -863,15 +866,20 @@ inline bool bx3_tn_eligible(const Bx3TnArgs& p) {
          32 * p.ldb < (1LL << 28);
 }
 
-inline void bx3_tn_launch(const Bx3TnArgs& p, hipStream_t s) {
+template <bool HALF>
+inline void bx3_tn_launch_t(const Bx3TnArgs& p, hipStream_t s) {
   static bool once = [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&bx3_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&bx3_tn_kernel<HALF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)kBx3TnLds) == hipSuccess;
   }();
   (void)once;
   const int quads = bx3_tn_quads(p.M, p.N);
   const unsigned grid = (unsigned)(((p.nchunks + 7) / 8) * 8 * quads);
-  hipLaunchKernelGGL(bx3_tn_kernel, dim3(grid), dim3(512), kBx3TnLds, s, p);
+  hipLaunchKernelGGL(bx3_tn_kernel<HALF>, dim3(grid), dim3(512), kBx3TnLds, s, p);
+}
+inline void bx3_tn_launch(const Bx3TnArgs& p, hipStream_t s) {
+  if (p.ab_half) bx3_tn_launch_t<true>(p, s);
+  else bx3_tn_launch_t<false>(p, s);
 }
 
 }  // namespace mms
