@@ -1101,7 +1101,28 @@ def other_configs(torch, capi):
         "us_per_step": us, "pairs_per_s": N / (us * 1e-6), "TFLOPs": (2.0 * N * K * K + 2.0 * N * K) / us / 1e6,
         "dtype": "f16 storage / exact bf16 x 2 x 3 products, f32 accumulate", "bound": "mfma (bf16 pipe) / L2->LDS operand stream",
         "note": "mms_simmatrix_forward_f16: scores only (no Q.W output); the fp32-storage forward above writes Q.W too"}
-    del q16, a16, W16
+    # ... and the training pair on 304 x 304 (both inner dimensions multiples of 8), next to the fp32-storage step of that shape
+    a16b = torch.zeros(N, 304, device="cuda", dtype=torch.float16); a16b[:, :K] = a.half()
+    W16b = torch.zeros(304, 304, device="cuda"); W16b[:K, :K] = W
+    qw16, dW16 = torch.empty(N, 304, device="cuda"), torch.zeros(304, 304, device="cuda")
+    dq16, da16 = torch.empty_like(q16), torch.empty_like(a16b)
+
+    def step16():
+        capi.simmatrix_forward_train_f16(q16, a16b, W16b, top, qw16, ws=ws)
+        capi.simmatrix_backward_f16(q16, a16b, W16b, qw16, dT, dq16, da16, dW16, ws=ws)
+    us16 = _graph_time(torch, step16, iters=16)
+    q32b, a32b = q16.float(), a16b.float()
+    dq32b, da32b = torch.empty_like(q32b), torch.empty_like(a32b)
+
+    def step32():
+        capi.simmatrix_forward(q32b, a32b, W16b, top, qw16, ws=ws)
+        capi.simmatrix_backward(q32b, a32b, W16b, dT, dq32b, da32b, dW16, ws=ws, qw=qw16)
+    us32 = _graph_time(torch, step32, iters=16)
+    out["simmatrix_training_16384x304x304_fp16_storage"] = {
+        "us_per_step": us16, "us_per_step_fp32_storage_same_shape": us32, "pairs_per_s": N / (us16 * 1e-6),
+        "dtype": "f16 storage (q, a, dq, da) / f32 W, dW, scores; exact bf16 splits, f32 accumulate",
+        "note": "mms_simmatrix_forward_train_f16 + mms_simmatrix_backward_f16"}
+    del q16, a16, W16, a16b, W16b, qw16, dW16, dq16, da16, q32b, a32b, dq32b, da32b
 
     def cfg3_nocache():
         capi.simmatrix_forward(q, a, W, top, scr, ws=ws)
