@@ -135,6 +135,19 @@ __device__ __forceinline__ Bx3Frag bx3_split8_half(const bx3_u4 raw) {
   return f;
 }
 
+// Eight floats that are widened halves -> the two planes that hold them exactly (no third level: 8 instead of 11 VALU a pair)
+__device__ __forceinline__ void bx3_split8_two(const float* x, bx3_u4& h, bx3_u4& m) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bx3_f2 v = {x[2 * i], x[2 * i + 1]};
+    const unsigned hh = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bx3_h2));
+    v.x = x[2 * i] - __builtin_bit_cast(float, hh << 16);
+    v.y = x[2 * i + 1] - __builtin_bit_cast(float, hh & 0xffff0000u);
+    h[i] = hh;
+    m[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bx3_h2));
+  }
+}
+
 // B(k, n) = B[k*b_k + n*b_n]  ->  image [k-step][column tile][plane][lane]; one thread per (k-step, column tile, lane).
 // Rider: zero[0 .. zero_n) = 0 (the row-dot output two column groups add into).
 struct Bx3SplitArgs {
@@ -789,9 +802,15 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
         float x[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = t >= 10 ? raw[R][u][j] * ksc[R][j] : raw[R][u][j];
+        bx3_u4* o = reinterpret_cast<bx3_u4*>(tn_lds + buf * BX3TN_BUF + t * 3072) + lane;
+        if (HALF && t < 10) {                               // the A side of the half form: widened halves, two planes (the third is
+          bx3_u4 h2, m2;                                    // never read: the compute waves skip its product)
+          bx3_split8_two(x, h2, m2);
+          o[0] = h2; o[64] = m2;
+          continue;
+        }
         const pg_v4f r0 = {x[0], x[1], x[2], x[3]}, r1 = {x[4], x[5], x[6], x[7]};
         const Bx3Frag f = bx3_split8(r0, r1);
-        bx3_u4* o = reinterpret_cast<bx3_u4*>(tn_lds + buf * BX3TN_BUF + t * 3072) + lane;
         o[0] = __builtin_bit_cast(bx3_u4, f.h); o[64] = __builtin_bit_cast(bx3_u4, f.m); o[128] = __builtin_bit_cast(bx3_u4, f.l);
       }
     };
@@ -830,7 +849,8 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
 #pragma unroll
     for (int a = 0; a < 5; ++a) {
       const bx3_u4* q = img + (5 * wr + a) * 192;
-      ah[a] = __builtin_bit_cast(bx3_h8, q[0]); am[a] = __builtin_bit_cast(bx3_h8, q[64]); al[a] = __builtin_bit_cast(bx3_h8, q[128]);
+      ah[a] = __builtin_bit_cast(bx3_h8, q[0]); am[a] = __builtin_bit_cast(bx3_h8, q[64]);
+      if (!HALF) al[a] = __builtin_bit_cast(bx3_h8, q[128]);
     }
 #pragma unroll
     for (int b = 0; b < 5; ++b) {
@@ -838,7 +858,7 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
       const bx3_h8 bh = __builtin_bit_cast(bx3_h8, q[0]), bm = __builtin_bit_cast(bx3_h8, q[64]), bl = __builtin_bit_cast(bx3_h8, q[128]);
 #pragma unroll
       for (int a = 0; a < 5; ++a) {
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[a], bh, acc[a][b], 0, 0, 0);
+        if (!HALF) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[a], bh, acc[a][b], 0, 0, 0);
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bl, acc[a][b], 0, 0, 0);
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[a], bm, acc[a][b], 0, 0, 0);
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[a], bh, acc[a][b], 0, 0, 0);
