@@ -31,11 +31,15 @@
 //     must have landed, one counted vmcnt + one barrier per step; the A lanes fetch (row l%32, 4 k) so that the compute
 //     wave's two ds_read_b128 are linear in the lane id;
 //   * a compute wave splits its A fragment in registers (44 VALU per k-step, issued in the shadow of 6 NTW MFMAs of
-//     32 cycles each: unlike the fp32 MFMA, the bf16 MFMA holds vector issue for 8 of its 32 cycles only); the next
-//     step's A fragment and the next tile's B fragments are read while the current tile's MFMAs run;
+//     32 cycles each: unlike the fp32 MFMA, the bf16 MFMA holds vector issue for 8 of its 32 cycles only -- measured
+//     cost 2.6-2.9 cycles per VALU all the same, tools/bx3struct.hip); the next step's A fragment and B fragments are
+//     read while the current step's MFMAs run;
 //   * epilogue as panel_gemm.h: accumulators through LDS, 16-byte row-segment stores, the per-row scale and the
 //     row dot of the SimMatrix forward folded in (two column groups: each adds its half of the row dot to a zeroed
-//     output -- two addends, so the sum does not depend on who arrives first).
+//     output -- two addends, so the sum does not depend on who arrives first);
+//   * the loader waves also carry the backward's streaming side job (Bx3Side) and request the row dot's operand
+//     ahead of the epilogue; AH = true is the fp16-STORAGE form (A, Y and optionally C as halves: two planes, five
+//     products).  Further down: bx3_tn_kernel, the weight gradient (both operands activations, split-K).
 #ifndef MMS_BX3_GEMM_H_
 #define MMS_BX3_GEMM_H_
 
