@@ -729,23 +729,29 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
 
   if (wave >= 4) {
     // ------------------------------ splitter waves ------------------------------
-    const int w = wave - 4, c = lane & 15, g = lane >> 4;
-    // tiles w, w + 4, ... of the 20: tile t < 10 is columns [i0 + 16 t, +16) of A, else [j0 + 16 (t - 10), +16) of B
-    const float* xb[5];                 // the tile's operand (wave-uniform)
+    // Units of 32 columns x 16 pairs (so that a load covers 128 contiguous bytes of a row: with 16-column units the
+    // 64-byte segments of 1,200-byte rows straddled two sectors each): unit U = 2 P + h, P < 5: columns [i0 + 32 P, +32)
+    // of A, else [j0 + 32 (P - 5), +32) of B; h = which 16 pairs of the step.  Lane (c32 = l % 32, g2 = l / 32) holds
+    // column c32's pairs 16 h + 8 g2 + j -- the fragment of 16-column tile 2 P + c32 / 16, lane slot (c32 % 16, k group
+    // 2 h + g2).  Wave w takes units w, w + 4, ..., w + 16: all of k half h = w & 1.
+    const int w = wave - 4, c32 = lane & 31, g2 = lane >> 5, hk = w & 1;
+    const int g = 2 * hk + g2;          // the lane's k group of the 32-pair step
+    const float* xb[5];                 // the unit's operand (wave-uniform)
     long long ld[5];
-    unsigned offl[5];                   // the lane's BYTE offset inside a step's 32 rows: 8 g rows down, its column
     int colc[5];
+    unsigned ldsoff[5];                 // byte offset of the lane's 16 bytes inside an image buffer (plane h; m, l: + 1024, 2048)
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
-      const int t = w + 4 * u;
-      const bool isb = t >= 10;
-      int col = isb ? j0 + 16 * (t - 10) + c : i0 + 16 * t + c;
+      const int P = (w + 4 * u) >> 1;
+      const bool isb = P >= 5;
+      int col = isb ? j0 + 32 * (P - 5) + c32 : i0 + 32 * P + c32;
       const int lim = isb ? p.N : p.M;
       col = col < lim ? col : lim - 1;                 // columns past the edge: a valid column's values (outputs never stored)
       xb[u] = isb ? p.B : p.A;
       ld[u] = isb ? p.ldb : p.lda;
       colc[u] = col;
-      offl[u] = (unsigned)((8 * g * ld[u] + col) * 4);   // bytes
+      const int t = 2 * P + (c32 >> 4);                // (P >= 5: tiles 10..19 are the B side, as before)
+      ldsoff[u] = (unsigned)(t * 3072 + ((c32 & 15) + 16 * g) * 16);
     }
     // two register stages: step s + 2 is requested BEFORE step s + 1 is split, a whole step ahead of its use
     float raw[2][5][8], ksc[2][8];
@@ -802,12 +808,12 @@ __global__ __launch_bounds__(512, 1) void bx3_tn_kernel(const Bx3TnArgs p) {
 #endif
 #pragma unroll
       for (int u = 0; u < 5; ++u) {
-        const int t = w + 4 * u;
+        const bool isb = ((w + 4 * u) >> 1) >= 5;           // wave-uniform
         float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = t >= 10 ? raw[R][u][j] * ksc[R][j] : raw[R][u][j];
-        bx3_u4* o = reinterpret_cast<bx3_u4*>(tn_lds + buf * BX3TN_BUF + t * 3072) + lane;
-        if (HALF && t < 10) {                               // the A side of the half form: widened halves, two planes (the third is
+        for (int j = 0; j < 8; ++j) x[j] = isb ? raw[R][u][j] * ksc[R][j] : raw[R][u][j];
+        bx3_u4* o = reinterpret_cast<bx3_u4*>(tn_lds + buf * BX3TN_BUF + ldsoff[u]);
+        if (HALF && !isb) {                               // the A side of the half form: widened halves, two planes (the third is
           bx3_u4 h2, m2;                                    // never read: the compute waves skip its product)
           bx3_split8_two(x, h2, m2);
           o[0] = h2; o[64] = m2;
