@@ -40,6 +40,14 @@ def test_workspace_queries_are_host_only(hiplib):
     assert hiplib.mms_triplet_workspace_bytes(4096) == 1056 * 8 + 4096 * 4   # arrival words, then one term per triplet
     assert hiplib.mms_triplet_workspace_init(None, 0, None) == 3             # MMS_ERR_WORKSPACE, nothing enqueued
     assert hiplib.mms_simmatrix_workspace_bytes(16384, 300, 300) > 16384 * 300 * 4
+    # ... and holds the operand image of the bf16 pipe: 19 k-steps x 10 column tiles x 3 planes x 1 KB for W (300, 300),
+    # next to the split-K slabs of dW (64 chunks at 16384 pairs) and the fp32 path's W^T
+    sm = hiplib.mms_simmatrix_workspace_bytes(16384, 300, 300)
+    assert sm >= 16384 * 300 * 4 + 64 * 300 * 300 * 4 + 300 * 300 * 4 + 19 * 10 * 3 * 1024
+    assert hiplib.mms_simmatrix_workspace_bytes(16384, 304, 300) >= sm          # grows with the shape
+    # entry points that need a workspace say so without one (host-side checks only; no launch)
+    assert hiplib.mms_simmatrix_forward_ws_f32(8, 4, 4, 1, 1, 1, 1, 1, None, 0, None) == 3
+    assert hiplib.mms_set_matrix_mode(7) == 1 and hiplib.mms_get_matrix_mode() == 0
 
 
 def test_code_object_is_gfx950_only():
