@@ -643,6 +643,50 @@ class EmbedLayer : public Layer<Dtype> {
   int M_ = 0, K_ = 0, N_ = 0;
   bool bias_term_ = true;
   Blob<Dtype> workspace_;
+
+ public:
+  // Two Embed layers over ONE table and bias (network_v4's w2v_q / w2v_a, shared by parameter name), run as a pair by
+  // PathNet: `later` is the layer that comes later in the net file -- Net::Backward reaches it first, so it is layer 0
+  // of both calls (include/mms.h: mms_embed_forward_pair_f32 / mms_embed_backward_pair[_indexed]_f32; the bits are those
+  // of the two layers run one after the other).  index_ws: the pair's inverted index, built beside the forward's gathers.
+  static bool PairForward(EmbedLayer<float>& later, EmbedLayer<float>& earlier, const vector<Blob<float>*>& bl,
+                          const vector<Blob<float>*>& tl, const vector<Blob<float>*>& be, const vector<Blob<float>*>& te,
+                          Blob<float>* index_ws, bool* indexed) {
+    later.Reshape(bl, tl);
+    earlier.Reshape(be, te);
+    if (later.N_ != earlier.N_ || later.K_ != earlier.K_ || later.bias_term_ != earlier.bias_term_) return false;
+    const size_t need = mms_embed_workspace_bytes(later.M_ + earlier.M_, later.N_);
+    index_ws->Reshape(vector<int>{(int)((need + sizeof(float) - 1) / sizeof(float))});
+    *indexed = mms_embed_pair_index_supported(later.M_, earlier.M_, later.K_) != 0;
+    mms_check(mms_embed_forward_pair_f32(later.M_, earlier.M_, later.N_, later.K_, bl[0]->gpu_data(), be[0]->gpu_data(),
+                                         later.blobs_[0]->gpu_data(),
+                                         later.bias_term_ ? later.blobs_[1]->gpu_data() : nullptr,
+                                         tl[0]->mutable_gpu_data(), te[0]->mutable_gpu_data(),
+                                         *indexed ? index_ws->mutable_gpu_data() : nullptr,
+                                         *indexed ? (size_t)index_ws->count() * sizeof(float) : 0, nullptr),
+              "mms_embed_forward_pair_f32");
+    return true;
+  }
+  static void PairBackward(EmbedLayer<float>& later, EmbedLayer<float>& earlier, const vector<Blob<float>*>& bl,
+                           const vector<Blob<float>*>& tl, const vector<Blob<float>*>& be, const vector<Blob<float>*>& te,
+                           Blob<float>* index_ws, bool indexed) {
+    const bool pw = later.param_propagate_down_[0];
+    const bool pb = later.bias_term_ && later.param_propagate_down_[1];
+    if (!pw && !pb) return;
+    float* wd = pw ? later.blobs_[0]->mutable_gpu_diff() : nullptr;
+    float* bd = pb ? later.blobs_[1]->mutable_gpu_diff() : nullptr;
+    const size_t wsb = (size_t)index_ws->count() * sizeof(float);
+    if (indexed)
+      mms_check(mms_embed_backward_pair_indexed_f32(later.M_, earlier.M_, later.N_, later.K_, bl[0]->gpu_data(),
+                                                    tl[0]->gpu_diff(), be[0]->gpu_data(), te[0]->gpu_diff(), wd, bd,
+                                                    index_ws->mutable_gpu_data(), wsb, nullptr),
+                "mms_embed_backward_pair_indexed_f32");
+    else
+      mms_check(mms_embed_backward_pair_f32(later.M_, earlier.M_, later.N_, later.K_, bl[0]->gpu_data(), tl[0]->gpu_diff(),
+                                            be[0]->gpu_data(), te[0]->gpu_diff(), wd, bd, index_ws->mutable_gpu_data(), wsb,
+                                            nullptr),
+                "mms_embed_backward_pair_f32");
+  }
 };
 INSTANTIATE_CLASS(EmbedLayer);
 REGISTER_LAYER_CLASS(Embed);
@@ -1320,6 +1364,7 @@ class PathNet {
   // bottoms come from Embed layers that read ONE table (shared by parameter name, as network_v4's do) and feed
   // nothing else is run straight from the word ids -- the (N, W, D) blobs are never written.
   bool SetOption(const string& key, int value) {
+    if (key == "pair_embed") { pair_embed_ = value != 0; return true; }
     if (key != "fuse_embed_scoring") return false;
     fuse_embed_ = value != 0;
     plan_fusion();
@@ -1328,12 +1373,29 @@ class PathNet {
   int num_fused() const { return (int)fused_.size(); }
   float Forward() {
     float loss = 0;
+    pair_done_.clear();
+    for (auto& kv : pair_state_) kv.second.ran = false;
     for (size_t i = 0; i < layers_.size(); ++i) {
       PathNetLayer& L = layers_[i];
       if (!L.runnable || skipped_.count(i)) continue;
       for (Split& sp : splits_)                                    // SplitLayer::Reshape: the tops share the bottom's data
         for (size_t c = 0; c < sp.consumers.size(); ++c)
           if (sp.consumers[c].first == i) { sp.alias[c]->ReshapeLike(*sp.orig); sp.alias[c]->ShareData(*sp.orig); }
+      if (pair_done_.count(i)) continue;                 // the later Embed of a pair: written with the earlier one
+      auto ep = embed_pairs_.find(i);
+      if (ep != embed_pairs_.end() && pair_embed_) {
+        // two Embed layers over one table: both gathers in one launch, the backward's inverted index built beside them
+        PathNetLayer& Lj = layers_[ep->second];
+        EmbedPairState& st = pair_state_[i];
+        if (EmbedLayer<float>::PairForward(*static_cast<EmbedLayer<float>*>(Lj.layer.get()),
+                                           *static_cast<EmbedLayer<float>*>(L.layer.get()), Lj.bottom, Lj.top, L.bottom, L.top,
+                                           &st.index_ws, &st.indexed)) {
+          st.ran = true;
+          pair_done_.insert(ep->second);
+          continue;
+        }
+        st.ran = false;
+      }
       auto f = fused_.find(i);
       if (f != fused_.end()) {
         PathNetLayer& Eq = layers_[f->second.first];
@@ -1359,6 +1421,15 @@ class PathNet {
       for (Split& sp : splits_) if (sp.producer == (int)i) split_backward(sp);     // every consumer has run by now
       if (!L.runnable) continue;
       if (!has_backward(L)) continue;
+      if (pair_done_.count(i)) continue;                 // the later Embed of a pair: its Backward runs with the earlier one's,
+      auto ep = embed_pairs_.find(i);                    // when every consumer of BOTH tops has run
+      if (ep != embed_pairs_.end() && pair_state_[i].ran) {
+        PathNetLayer& Lj = layers_[ep->second];
+        EmbedLayer<float>::PairBackward(*static_cast<EmbedLayer<float>*>(Lj.layer.get()),
+                                        *static_cast<EmbedLayer<float>*>(L.layer.get()), Lj.bottom, Lj.top, L.bottom, L.top,
+                                        &pair_state_[i].index_ws, pair_state_[i].indexed);
+        continue;
+      }
       vector<bool> pd(L.bottom.size(), true);
       for (size_t b = 0; b < L.bottom.size(); ++b) pd[b] = propagates(L, b);
       L.layer->Backward(L.top, pd, L.bottom);
@@ -1464,7 +1535,35 @@ class PathNet {
     mms_check(mms_split_backward_f32(sp.orig->count(), (int)tops.size(), tops.data(), sp.orig->mutable_gpu_diff(), nullptr),
               "mms_split_backward_f32");
   }
+  // Pairs of Embed layers that read ONE table (and bias) by parameter name, the later one's word ids available when
+  // the earlier one runs: forward as one launch, backward as one pass (EmbedLayer::PairForward / PairBackward; option
+  // "pair_embed", on by default -- the results are the two layers' bits, so nothing observable changes but the time).
+  void plan_embed_pairs() {
+    embed_pairs_.clear();
+    pair_state_.clear();
+    std::set<size_t> taken;
+    for (size_t i = 0; i < layers_.size(); ++i) {
+      PathNetLayer& Li = layers_[i];
+      if (!Li.runnable || Li.param.type() != "Embed" || taken.count(i) || Li.bottom.size() != 1 || Li.top.size() != 1) continue;
+      for (size_t j = i + 1; j < layers_.size(); ++j) {
+        PathNetLayer& Lj = layers_[j];
+        if (!Lj.runnable || Lj.param.type() != "Embed" || taken.count(j) || Lj.bottom.size() != 1 || Lj.top.size() != 1) continue;
+        auto &bi = Li.layer->blobs(), &bj = Lj.layer->blobs();
+        if (bi.empty() || bi.size() != bj.size() || bi[0].get() != bj[0].get()) continue;
+        if (bi.size() > 1 && bi[1].get() != bj[1].get()) continue;
+        bool ready = true;                               // the later layer's ids must exist when the earlier layer runs
+        for (size_t k = i; k < layers_.size() && ready; ++k)
+          for (Blob<float>* t : layers_[k].top) if (t == Lj.bottom[0]) ready = false;
+        if (!ready) continue;
+        embed_pairs_[i] = j;
+        pair_state_[i];
+        taken.insert(i); taken.insert(j);
+        break;
+      }
+    }
+  }
   void plan_fusion() {
+    plan_embed_pairs();
     fused_.clear();
     skipped_.clear();
     if (!fuse_embed_) return;
@@ -1497,7 +1596,11 @@ class PathNet {
   }
   string name_;
   int phase_;
-  bool fuse_embed_ = false, ran_fused_ = false;
+  bool fuse_embed_ = false, ran_fused_ = false, pair_embed_ = true;
+  struct EmbedPairState { Blob<float> index_ws; bool indexed = false, ran = false; };
+  std::map<size_t, size_t> embed_pairs_;                 // earlier Embed layer -> the later one over the same table
+  std::map<size_t, EmbedPairState> pair_state_;
+  std::set<size_t> pair_done_;                           // later layers of pairs that ran as pairs in this Forward
   std::map<size_t, std::pair<size_t, size_t> > fused_;   // SimCross layer -> its two Embed producers
   std::set<size_t> skipped_;
   vector<PathNetLayer> layers_;

@@ -941,9 +941,9 @@ int simcross_euclid_rows_f16(int N, int D, const void* q, const void* a, const f
 #define MMS_F16_LCW(n, w)                                                                             \
   do {                                                                                                \
     static bool once = [] {                                                                           \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&euclid_rows_lanechain_f16_kernel<n, true, w>),  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&euclid_rows_lanechain_f16_kernel<n, true, w>),  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&euclid_rows_lanechain_f16_kernel<n, false, w>), \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&euclid_rows_lanechain_f16_kernel<n, false, w>), \
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
       return true;                                                                                    \
     }();                                                                                              \

@@ -161,6 +161,25 @@ def test_network_v4_path_layers_run_from_the_net_file(L, oracle, tmp_path):
     np.add.at(dtab, question[:B].astype(int).ravel(), dq_ref.reshape(-1, D))
     np.add.at(dtab, answer[:B].astype(int).ravel(), da_ref.reshape(-1, D))
     assert_close(eq.blobs[0].diff, dtab, 2e-4, "shared table diff")
+    # The two Embed layers ran as a PAIR (one forward launch, one backward pass from the index the forward built: the net's
+    # default, option "pair_embed"): the same net with the option off runs them one after the other -- same bits.
+    net4 = L.Net(open(FIXTURE).read().replace("__SOURCE__", str(src)), phase="TEST")
+    pb4 = net4.blob("prob"); pb4.reshape(B, 2); pb4.data[...] = prob
+    net4.set_option("pair_embed", 0)
+    assert net4.SetUp() == 7
+    for name, bi in (("w2v_q", 0), ("w2v_q", 1), ("sim_cross", 0), ("sim_cross", 1)):
+        net4.layer(name).blobs[bi].data[...] = net.layer(name).blobs[bi].data
+    net4.Forward()
+    assert_bitexact(net4.blob("w2v_q").data, q_ref)
+    assert_bitexact(net4.blob("w2v_a").data, a_ref)
+    net4.blob("sim_cross").diff[...] = dT
+    e4, s4 = net4.layer("w2v_q"), net4.layer("sim_cross")
+    for b in (s4.blobs[0], s4.blobs[1], e4.blobs[0], e4.blobs[1]):
+        b.diff[...] = 0
+    net4.Backward()
+    assert_bitexact(e4.blobs[0].diff, eq.blobs[0].diff, "table diff: pair == one after the other")
+    # (the bias gradient is a gemv in the reference, no defined order: the pair sums it over the concatenated rows)
+    assert_close(e4.blobs[1].diff, eq.blobs[1].diff, TOL, "Embed bias diff: pair vs one after the other")
     # the next Forward serves the file's second batch
     net.Forward()
     assert_bitexact(net.blob("question").data, question[B:].astype(np.float32))
