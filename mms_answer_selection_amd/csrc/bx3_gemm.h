@@ -342,6 +342,16 @@ __global__ __launch_bounds__(512, 1) void bx3_kernel(const Bx3Args p) {
   for (int t = 0; t < NTW; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  // the epilogue's per-row scales (two rows per lane: wave w writes rows 16 w .. 16 w + 15), requested now: in the
+  // epilogue the load would be a memory round trip in front of the stores
+  float scv[2] = {1.f, 1.f};
+  if (p.rowscale) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int gi = row0 + 16 * wave + 8 * pass + (lane >> 3);
+      scv[pass] = p.rowscale[gi < p.M ? gi : p.M - 1];
+    }
+  }
 
   if (wave >= 4) {
     // ------------------------------- loader waves -------------------------------
@@ -550,7 +560,7 @@ __global__ __launch_bounds__(512, 1) void bx3_kernel(const Bx3Args p) {
   for (int pass = 0; pass < 2; ++pass) {
     const int r = 16 * wave + 8 * pass + (lane >> 3), gi = row0 + r;
     const bool rok = gi < p.M;
-    const float sc = (p.rowscale && rok) ? p.rowscale[gi] : 1.f;
+    const float sc = scv[pass];
     pg_v4f y[NTW];
     if (p.Y) {
 #pragma unroll
